@@ -1,0 +1,261 @@
+"""ctypes loader for the CPU oracle (oracle/orlg_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+It takes plain numpy tables (the frozen topology CSR arrays and the cumulative-weight tables) so
+that it does not depend on the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_BIT_RATES = 64
+
+POLICY = {"sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4, "external": -1}
+
+
+class Topology(C.Structure):
+    _fields_ = [("num_nodes", C.c_int32), ("num_links", C.c_int32), ("k_paths", C.c_int32), ("num_paths", C.c_int32),
+                ("pair_path_base", C.c_void_p), ("pair_path_count", C.c_void_p), ("path_hops", C.c_void_p),
+                ("path_se", C.c_void_p), ("path_length", C.c_void_p), ("path_link_off", C.c_void_p),
+                ("path_links", C.c_void_p)]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_slots", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
+                ("j", C.c_int32), ("reward_mode", C.c_int32), ("pad0", C.c_int32),
+                ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double), ("channel_width", C.c_double),
+                ("bit_rates", C.c_void_p), ("bit_rate_cum", C.c_void_p), ("src_cum", C.c_void_p),
+                ("dst_cum", C.c_void_p)]
+
+
+class Request(C.Structure):
+    _fields_ = [("service_id", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("bit_rate", C.c_int32),
+                ("arrival_time", C.c_double), ("holding_time", C.c_double)]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("reward", C.c_double), ("done", C.c_int32), ("accepted", C.c_int32),
+                ("service_blocking_rate", C.c_double), ("episode_service_blocking_rate", C.c_double),
+                ("bit_rate_blocking_rate", C.c_double), ("episode_bit_rate_blocking_rate", C.c_double),
+                ("network_compactness", C.c_double), ("network_compactness_difference", C.c_double),
+                ("avg_link_compactness", C.c_double), ("avg_link_utilization", C.c_double),
+                ("fairness", C.c_double), ("bit_rate_blocking", C.c_double * MAX_BIT_RATES)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "services_processed", "services_accepted", "episode_services_processed", "episode_services_accepted",
+        "bit_rate_requested", "bit_rate_provisioned", "episode_bit_rate_requested", "episode_bit_rate_provisioned")]
+
+
+TRACE_FIELDS = [
+    ("service_id", np.int32), ("src", np.int32), ("dst", np.int32), ("bit_rate", np.int32),
+    ("act_path", np.int32), ("act_slot", np.int32), ("arrival", np.float64), ("holding", np.float64),
+    ("accepted", np.uint8), ("done", np.uint8), ("reward", np.float64),
+    ("services_processed", np.int64), ("services_accepted", np.int64),
+    ("episode_services_processed", np.int64), ("episode_services_accepted", np.int64),
+    ("bit_rate_requested", np.int64), ("bit_rate_provisioned", np.int64),
+    ("episode_bit_rate_requested", np.int64), ("episode_bit_rate_provisioned", np.int64),
+    ("network_compactness", np.float64), ("network_compactness_difference", np.float64),
+    ("avg_link_compactness", np.float64), ("avg_link_utilization", np.float64),
+    ("fairness", np.float64), ("current_time", np.float64), ("graph_throughput", np.float64),
+    ("graph_compactness", np.float64), ("free_total", np.int64), ("obs", np.float64),
+]
+
+
+class Trace(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _ in TRACE_FIELDS]
+
+
+def build(asan=False):
+    target = "liborlg_oracle_asan.so" if asan else "liborlg_oracle.so"
+    subprocess.run(["make", "-s", "-C", HERE, target], check=True)
+    return os.path.join(HERE, target)
+
+
+_LIB = {}
+
+
+def lib(asan=False):
+    if asan not in _LIB:
+        path = os.path.join(HERE, "liborlg_oracle_asan.so" if asan else "liborlg_oracle.so")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(HERE, "orlg_oracle.c")):
+            build(asan)
+        L = C.CDLL(path)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(Topology), C.POINTER(Config), C.c_uint64]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_reset.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_request.argtypes = [C.c_void_p, C.POINTER(Request)]
+        L.orc_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(StepResult)]
+        L.orc_step_deeprmsa.argtypes = [C.c_void_p, C.c_int, C.POINTER(StepResult)]
+        L.orc_policy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.orc_current_time.restype = C.c_double
+        L.orc_current_time.argtypes = [C.c_void_p]
+        L.orc_get_available_slots.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_link_stats.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_get_graph_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3
+        L.orc_get_bit_rate_hist.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orc_num_running.argtypes = [C.c_void_p]
+        L.orc_deeprmsa_observation.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_number_slots.argtypes = [C.c_void_p, C.c_int]
+        L.orc_is_path_free.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_get_available_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.POINTER(Trace)]
+        L.orc_py_random_stream.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+        _LIB[asan] = L
+    return _LIB[asan]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEnv:
+    """One reference-semantics environment on the CPU.
+
+    ``tables`` is a dict of numpy arrays: pair_path_base, pair_path_count, path_hops, path_se,
+    path_length, path_link_off, path_links (int32 / float64) and num_nodes, num_links, k_paths.
+    """
+
+    def __init__(self, tables, *, num_slots, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
+                 arrival_lambda, holding_lambda, channel_width=12.5, j=1, reward_mode=0, seed=41, asan=False):
+        self.L = lib(asan)
+        self._keep = []
+
+        def keep(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            self._keep.append(a)
+            return a
+
+        t = Topology()
+        t.num_nodes, t.num_links, t.k_paths = int(tables["num_nodes"]), int(tables["num_links"]), int(tables["k_paths"])
+        t.num_paths = len(tables["path_hops"])
+        for name, dt in (("pair_path_base", np.int32), ("pair_path_count", np.int32), ("path_hops", np.int32),
+                         ("path_se", np.int32), ("path_length", np.float64), ("path_link_off", np.int32),
+                         ("path_links", np.int32)):
+            setattr(t, name, _ptr(keep(tables[name], dt)))
+        c = Config()
+        c.num_slots, c.episode_length, c.num_bit_rates = int(num_slots), int(episode_length), len(bit_rates)
+        c.j, c.reward_mode = int(j), int(reward_mode)
+        c.arrival_lambda, c.holding_lambda, c.channel_width = float(arrival_lambda), float(holding_lambda), float(channel_width)
+        c.bit_rates = _ptr(keep(bit_rates, np.int32))
+        c.bit_rate_cum = _ptr(keep(bit_rate_cum, np.float64))
+        c.src_cum = _ptr(keep(src_cum, np.float64))
+        c.dst_cum = _ptr(keep(dst_cum, np.float64))
+        self.N, self.E, self.K, self.S, self.j = t.num_nodes, t.num_links, t.k_paths, int(num_slots), int(j)
+        self.num_bit_rates = len(bit_rates)
+        self.obs_dim = 1 + 2 * self.N + (2 * self.j + 3) * self.K
+        self._t, self._c = t, c
+        self.h = self.L.orc_create(C.byref(t), C.byref(c), C.c_uint64(int(seed)))
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, only_episode_counters=True):
+        self.L.orc_reset(self.h, 1 if only_episode_counters else 0)
+
+    def request(self):
+        r = Request()
+        self.L.orc_get_request(self.h, C.byref(r))
+        return r
+
+    def step(self, path, slot):
+        r = StepResult()
+        self.L.orc_step(self.h, int(path), int(slot), C.byref(r))
+        return r
+
+    def step_deeprmsa(self, action):
+        r = StepResult()
+        self.L.orc_step_deeprmsa(self.h, int(action), C.byref(r))
+        return r
+
+    def policy(self, name):
+        p, s = C.c_int(), C.c_int()
+        self.L.orc_policy(self.h, POLICY[name], C.byref(p), C.byref(s))
+        return p.value, s.value
+
+    def counters(self):
+        c = Counters()
+        self.L.orc_get_counters(self.h, C.byref(c))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def current_time(self):
+        return self.L.orc_current_time(self.h)
+
+    def available_slots(self):
+        a = np.zeros((self.E, self.S), np.uint8)
+        self.L.orc_get_available_slots(self.h, _ptr(a))
+        return a
+
+    def link_stats(self):
+        out = [np.zeros(self.E) for _ in range(4)]
+        self.L.orc_get_link_stats(self.h, *[_ptr(a) for a in out])
+        return dict(zip(("utilization", "external_fragmentation", "compactness", "last_update"), out))
+
+    def graph_stats(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.L.orc_get_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return {"throughput": a.value, "compactness": b.value, "last_update": c.value}
+
+    def bit_rate_hist(self):
+        out = [np.zeros(self.num_bit_rates, np.int64) for _ in range(4)]
+        self.L.orc_get_bit_rate_hist(self.h, *[_ptr(a) for a in out])
+        return dict(zip(("requested", "provisioned", "episode_requested", "episode_provisioned"), out))
+
+    def num_running(self):
+        return self.L.orc_num_running(self.h)
+
+    def observation(self):
+        o = np.zeros(self.obs_dim)
+        self.L.orc_deeprmsa_observation(self.h, _ptr(o))
+        return o
+
+    def number_slots(self, idp):
+        return self.L.orc_get_number_slots(self.h, idp)
+
+    def is_path_free(self, idp, s, n):
+        return bool(self.L.orc_is_path_free(self.h, idp, s, n))
+
+    def available_blocks(self, idp):
+        st, ln = np.zeros(64, np.int32), np.zeros(64, np.int32)
+        n = self.L.orc_get_available_blocks(self.h, idp, _ptr(st), _ptr(ln))
+        return st[:n].copy(), ln[:n].copy()
+
+    def run(self, policy, n_steps, reset_on_done=False, actions=None, fields=None, with_obs=False):
+        """Returns a dict of per-step arrays (see TRACE_FIELDS). ``fields=[]`` records nothing (timing)."""
+        tr = Trace()
+        out = {}
+        for name, dt in TRACE_FIELDS:
+            if name == "obs":
+                if with_obs:
+                    out[name] = np.zeros((n_steps, self.obs_dim), dt)
+                    setattr(tr, name, _ptr(out[name]))
+                continue
+            if fields is None or name in fields:
+                out[name] = np.zeros(n_steps, dt)
+                setattr(tr, name, _ptr(out[name]))
+        ap = None
+        if actions is not None:
+            actions = np.ascontiguousarray(actions, np.int32)
+            ap = _ptr(actions)
+        self.L.orc_run(self.h, POLICY[policy], int(n_steps), 1 if reset_on_done else 0, ap, C.byref(tr))
+        return out
+
+
+def py_random_stream(seed, n):
+    out = np.zeros(n)
+    lib().orc_py_random_stream(C.c_uint64(seed), n, _ptr(out))
+    return out

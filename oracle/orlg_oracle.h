@@ -1,0 +1,139 @@
+/*
+ * oracle/orlg_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-environment, CPU restatement of the reference's RMSA / DeepRMSA step() path
+ * (optical_rl_gym/envs/{optical_network_env,rmsa_env,deeprmsa_env}.py).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (optical-rl-gym-qot-aware_amd/) never includes, links or calls it.
+ *
+ * Parity pin: checked bit-for-bit against the golden traces under tests/golden/ that were
+ * produced by running the unmodified reference in the build container
+ * (tests/golden/make_golden.py), see tests/test_oracle_golden.py.
+ *
+ * The representation is deliberately the reference's own (one byte per slot, run-length
+ * encoding for the fragmentation statistics, a binary heap of release events), NOT the
+ * bitmap representation the HIP kernels use, so that the two are independent derivations.
+ */
+#ifndef ORLG_ORACLE_H
+#define ORLG_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frozen topology (what the reference keeps in topology.graph["ksp"] etc.;
+ * create_topology.py:96-147, graph_utils.py:89-116). ksp[a,b] and ksp[b,a] share records. */
+typedef struct orc_topology {
+    int32_t num_nodes, num_links, k_paths, num_paths;
+    const int32_t *pair_path_base;  /* [N*N] first path record of ordered pair (s,d); -1 on the diagonal */
+    const int32_t *pair_path_count; /* [N*N] */
+    const int32_t *path_hops;       /* [num_paths] */
+    const int32_t *path_se;         /* [num_paths] best_modulation.spectral_efficiency */
+    const double *path_length;      /* [num_paths] km */
+    const int32_t *path_link_off;   /* [num_paths+1] CSR into path_links */
+    const int32_t *path_links;      /* edge attr "index" per hop */
+} orc_topology;
+
+typedef struct orc_config {
+    int32_t num_slots;       /* num_spectrum_resources */
+    int32_t episode_length;
+    int32_t num_bit_rates;
+    int32_t j;               /* DeepRMSA blocks per path (deeprmsa_env.py:34) */
+    int32_t reward_mode;     /* 0: 1/0 (optical_network_env.py:213); 1: +1/-1 (deeprmsa_env.py:123) */
+    int32_t pad0;
+    double arrival_lambda;   /* 1 / mean_service_inter_arrival_time  (rmsa_env.py:646-648) */
+    double holding_lambda;   /* 1 / mean_service_holding_time        (rmsa_env.py:651) */
+    double channel_width;    /* 12.5 */
+    const int32_t *bit_rates;   /* [num_bit_rates] */
+    const double *bit_rate_cum; /* [num_bit_rates] list(accumulate(bit_rate_probabilities)) */
+    const double *src_cum;      /* [N]   list(accumulate(node_request_probabilities)) */
+    const double *dst_cum;      /* [N*N] row s: accumulate(p with p[s]=0, renormalised) (optical_network_env.py:201-206) */
+} orc_config;
+
+enum { ORC_POLICY_SP_FF = 0, ORC_POLICY_SAP_FF = 1, ORC_POLICY_LLP_FF = 2,
+       ORC_POLICY_DEEPRMSA_SP_FF = 3, ORC_POLICY_DEEPRMSA_SAP_FF = 4 };
+
+#define ORC_MAX_BIT_RATES 64
+
+typedef struct orc_request {
+    int32_t service_id, src, dst, bit_rate;
+    double arrival_time, holding_time;
+} orc_request;
+
+typedef struct orc_step_result {
+    double reward;
+    int32_t done, accepted;
+    /* info dict of rmsa_env.py:293-332 */
+    double service_blocking_rate, episode_service_blocking_rate;
+    double bit_rate_blocking_rate, episode_bit_rate_blocking_rate;
+    double network_compactness, network_compactness_difference;
+    double avg_link_compactness, avg_link_utilization;
+    double fairness;
+    double bit_rate_blocking[ORC_MAX_BIT_RATES];
+} orc_step_result;
+
+typedef struct orc_counters {
+    int64_t services_processed, services_accepted;
+    int64_t episode_services_processed, episode_services_accepted;
+    int64_t bit_rate_requested, bit_rate_provisioned;
+    int64_t episode_bit_rate_requested, episode_bit_rate_provisioned;
+} orc_counters;
+
+typedef struct orc_env orc_env;
+
+orc_env *orc_create(const orc_topology *topo, const orc_config *cfg, uint64_t seed);
+void orc_destroy(orc_env *e);
+void orc_reset(orc_env *e, int only_episode_counters);
+void orc_get_request(const orc_env *e, orc_request *out);
+/* RMSAEnv.step([path, initial_slot]) (rmsa_env.py:222-341) */
+void orc_step(orc_env *e, int path, int initial_slot, orc_step_result *out);
+/* DeepRMSAEnv.step(action) (deeprmsa_env.py:48-58) */
+void orc_step_deeprmsa(orc_env *e, int action, orc_step_result *out);
+/* heuristics rmsa_env.py:854-937 (ids 0..2, write (path, slot)) and deeprmsa_env.py:135-155 (ids 3,4, write path = action) */
+void orc_policy(orc_env *e, int policy, int *path, int *slot);
+void orc_get_counters(const orc_env *e, orc_counters *out);
+double orc_current_time(const orc_env *e);
+/* copies topology.graph["available_slots"] as E*S bytes (1 = free) */
+void orc_get_available_slots(const orc_env *e, uint8_t *out);
+/* per-link time-weighted stats (rmsa_env.py:562-641), arrays of E doubles each */
+void orc_get_link_stats(const orc_env *e, double *utilization, double *external_fragmentation,
+                        double *compactness, double *last_update);
+void orc_get_graph_stats(const orc_env *e, double *throughput, double *compactness, double *last_update);
+/* histograms keyed by bit-rate index: requested, provisioned, episode requested, episode provisioned */
+void orc_get_bit_rate_hist(const orc_env *e, int64_t *req, int64_t *prov, int64_t *ereq, int64_t *eprov);
+int orc_num_running(const orc_env *e);
+/* DeepRMSAEnv.observation() (deeprmsa_env.py:60-121); out has 1 + 2N + (2j+3)k doubles */
+void orc_deeprmsa_observation(orc_env *e, double *out);
+/* query helpers used by tests */
+int orc_get_number_slots(const orc_env *e, int path_index);
+int orc_is_path_free(const orc_env *e, int path_index, int initial_slot, int number_slots);
+int orc_get_available_blocks(orc_env *e, int path_index, int *starts, int *lengths);
+
+/*
+ * Drive n_steps of "action = policy(env); env.step(action); if done and reset_on_done: env.reset()"
+ * (utils.py:134-149 without its arity bug).  Every trace pointer may be NULL.
+ * policy < 0: actions are taken from actions_in[2*i], actions_in[2*i+1].
+ */
+typedef struct orc_trace {
+    int32_t *service_id, *src, *dst, *bit_rate, *act_path, *act_slot;
+    double *arrival, *holding;
+    uint8_t *accepted, *done;
+    double *reward;
+    int64_t *services_processed, *services_accepted, *episode_services_processed, *episode_services_accepted;
+    int64_t *bit_rate_requested, *bit_rate_provisioned, *episode_bit_rate_requested, *episode_bit_rate_provisioned;
+    double *network_compactness, *network_compactness_difference, *avg_link_compactness, *avg_link_utilization;
+    double *fairness, *current_time, *graph_throughput, *graph_compactness;
+    int64_t *free_total;
+    double *obs; /* DeepRMSA observation AFTER each step, obs_dim doubles per step, or NULL */
+} orc_trace;
+void orc_run(orc_env *e, int policy, int64_t n_steps, int reset_on_done, const int32_t *actions_in,
+             orc_trace *tr);
+
+/* CPython random.Random(seed).random() stream, for known-answer tests */
+void orc_py_random_stream(uint64_t seed, int n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_topology(name):
+    from optical_rl_gym_amd import FrozenTopology
+
+    return FrozenTopology.from_json(os.path.join(GOLDEN, "topologies", name + ".json"))
+
+
+def topology_tables(topo):
+    return dict(num_nodes=topo.num_nodes, num_links=topo.num_links, k_paths=topo.k_paths,
+                pair_path_base=topo.pair_path_base, pair_path_count=topo.pair_path_count,
+                path_hops=topo.path_hops, path_se=topo.path_se, path_length=topo.path_length,
+                path_link_off=topo.path_link_off, path_links=topo.path_links)
+
+
+DEFAULT_BIT_RATES = [200, 250, 300, 350, 400, 450, 500, 550, 600, 650, 700, 750, 800, 850, 900, 950, 1000,
+                     1050, 1100, 1150, 1200]
+
+
+def oracle_env_from_kwargs(topo, env_kwargs, seed=None, j=1, reward_mode=0, asan=False):
+    """Build an oracle env from reference-style RMSAEnv kwargs (rmsa_env.py:29-53)."""
+    import oracle as orc
+    from optical_rl_gym_amd import selection_tables
+
+    kw = dict(env_kwargs)
+    bit_rates = kw.get("bit_rates", DEFAULT_BIT_RATES)
+    _, src_cum, dst_cum, br_cum = selection_tables(kw.get("node_request_probabilities"),
+                                                   kw.get("bit_rate_probabilities"), topo.num_nodes, bit_rates)
+    load, ht = kw.get("load", 10), kw.get("mean_service_holding_time", 10800.0)
+    # optical_network_env.py:127-129 ; rmsa_env.py:646-651
+    mean_iat = 1 / float(load / float(ht))
+    return orc.OracleEnv(topology_tables(topo), num_slots=kw.get("num_spectrum_resources", 100),
+                         episode_length=kw.get("episode_length", 1000), bit_rates=bit_rates, bit_rate_cum=br_cum,
+                         src_cum=src_cum, dst_cum=dst_cum, arrival_lambda=1 / mean_iat, holding_lambda=1 / ht,
+                         channel_width=kw.get("channel_width", 12.5), j=j, reward_mode=reward_mode,
+                         seed=kw.get("seed", 41) if seed is None else seed, asan=asan)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+@pytest.fixture(scope="session")
+def nsfnet():
+    return load_topology("nsfnet_chen_5-paths_6-modulations")
