@@ -1,0 +1,180 @@
+/*
+ * include/orlg.h -- C ABI of liborlg.so, the MI355X (gfx950) batched RMSA / DeepRMSA step() path.
+ *
+ * The reference (ehsan5890/optical-rl-gym-qot-aware) is pure Python and has NO native / FFI boundary
+ * (SURVEY.md section 0.1, 8b): the contract it defines is the gym.Env object surface.  This header is
+ * therefore the boundary a maintainer of the reference would bind with ctypes (INTEGRATION.md shows
+ * the stub); every entry point names the reference method(s) it replaces.  All citations are relative
+ * to the reference repository root.
+ *
+ * Conventions
+ *   - plain C types only; every function returns ORLG_OK (0) or a negative error code and never
+ *     throws; orlg_last_error() returns a thread-local message for the last failure.
+ *   - one handle = B independent environments on one HIP device and one stream; a handle is not
+ *     thread-safe; use one handle (one process) per GPU.
+ *   - the library owns all device state.  Array arguments are caller-owned and may be HOST or
+ *     DEVICE pointers (copies use hipMemcpyDefault on the handle's stream); tables passed to
+ *     orlg_create() are copied before it returns.
+ *   - there is no CPU fallback: without a HIP device orlg_create() fails with ORLG_ERR_NO_DEVICE.
+ */
+#ifndef ORLG_H
+#define ORLG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORLG_ABI_VERSION 1
+
+enum {
+    ORLG_OK = 0,
+    ORLG_ERR_INVALID = -1,     /* bad argument / unsupported size */
+    ORLG_ERR_NO_DEVICE = -2,   /* no HIP device or HIP runtime failure */
+    ORLG_ERR_HIP = -3,         /* a HIP call failed (message in orlg_last_error) */
+    ORLG_ERR_QUEUE_FULL = -4,  /* an environment's release queue overflowed (raise queue_capacity) */
+};
+
+/* Frozen topology: topology.graph["ksp"|"k_paths"|"node_indices"] + edge attr "index"
+ * (examples/create_topology.py:96-147, examples/graph_utils.py:89-116, optical_rl_gym/utils.py:27-36). */
+typedef struct orlg_topology {
+    int32_t num_nodes, num_links, k_paths, num_paths;
+    const int32_t *pair_path_base;  /* [N*N] first path record of ordered pair (src,dst); -1 on the diagonal */
+    const int32_t *pair_path_count; /* [N*N] must equal k_paths off the diagonal */
+    const int32_t *path_hops;       /* [num_paths] Path.hops */
+    const int32_t *path_se;         /* [num_paths] Path.best_modulation.spectral_efficiency */
+    const double *path_length;      /* [num_paths] Path.length (km) */
+    const int32_t *path_link_off;   /* [num_paths+1] CSR offsets into path_links */
+    const int32_t *path_links;      /* link "index" of every hop */
+} orlg_topology;
+
+/* Constructor kwargs of RMSAEnv / DeepRMSAEnv (optical_rl_gym/envs/rmsa_env.py:29-53,
+ * deeprmsa_env.py:10-32) after the host has turned weights into the cumulative tables CPython's
+ * random.choices builds (optical_network_env.py:197-206). */
+typedef struct orlg_rmsa_config {
+    int32_t num_slots;        /* num_spectrum_resources, 1..512 */
+    int32_t episode_length;
+    int32_t num_bit_rates;    /* 1..64 */
+    int32_t j;                /* DeepRMSA: blocks per path in action / observation (deeprmsa_env.py:34) */
+    int32_t reward_mode;      /* 0: 1/0 (optical_network_env.py:213-214); 1: +1/-1 (deeprmsa_env.py:123-124) */
+    int32_t queue_capacity;   /* release-queue slots per env, multiple of 64; 0 = pick from the load */
+    int32_t stats_level;      /* ORLG_STATS_* */
+    int32_t reserved;
+    double arrival_lambda;    /* 1 / mean_service_inter_arrival_time (rmsa_env.py:646-648) */
+    double holding_lambda;    /* 1 / mean_service_holding_time (rmsa_env.py:651) */
+    double channel_width;     /* GHz per slot, 12.5 (rmsa_env.py:46,708-719) */
+    const int32_t *bit_rates;   /* [num_bit_rates] */
+    const double *bit_rate_cum; /* [num_bit_rates] */
+    const double *src_cum;      /* [N] */
+    const double *dst_cum;      /* [N*N] row s = destination table given source s */
+} orlg_rmsa_config;
+
+enum {
+    ORLG_STATS_COUNTERS = 0, /* occupancy, queue, counters, histograms only */
+    ORLG_STATS_NETWORK = 1,  /* + network spectrum compactness per step and time-weighted graph
+                                throughput / compactness (rmsa_env.py:537-560, 806-851) */
+    ORLG_STATS_FULL = 2,     /* + per-link time-weighted utilization / external fragmentation /
+                                compactness (rmsa_env.py:562-641): everything RMSAEnv.step computes */
+};
+
+/* device-side policies: the reference's heuristic callbacks (rmsa_env.py:854-937, deeprmsa_env.py:135-155) */
+enum {
+    ORLG_POLICY_EXTERNAL = -1,        /* actions supplied by the caller */
+    ORLG_POLICY_SP_FF = 0,            /* shortest_path_first_fit */
+    ORLG_POLICY_SAP_FF = 1,           /* shortest_available_path_first_fit */
+    ORLG_POLICY_LLP_FF = 2,           /* least_loaded_path_first_fit */
+    ORLG_POLICY_DEEPRMSA_SP_FF = 3,   /* deeprmsa_env.shortest_path_first_fit (allow_rejection=False) */
+    ORLG_POLICY_DEEPRMSA_SAP_FF = 4,  /* deeprmsa_env.shortest_available_path_first_fit */
+    ORLG_POLICY_DEEPRMSA_EXTERNAL = 5 /* caller supplies Discrete(k*j) actions (deeprmsa_env.py:48-58) */
+};
+
+/* Optional per-step outputs of orlg_step(); any pointer may be NULL.  Arrays are [n_steps][B]
+ * (step-major) unless noted; with n_steps == 1 they are the usual per-env vectors. */
+typedef struct orlg_step_io {
+    int32_t *act_path;   /* action taken, path component (k = rejection) */
+    int32_t *act_slot;   /* action taken, initial slot (S = rejection) */
+    uint8_t *accepted;   /* current_service.accepted */
+    uint8_t *done;       /* episode_services_processed == episode_length (rmsa_env.py:339) */
+    double *reward;      /* reward() */
+    int32_t *request;    /* [n_steps][B][4] service_id, source_id, destination_id, bit_rate of the request served */
+    double *arrival;     /* its arrival_time */
+    double *holding;     /* its holding_time */
+    double *network_compactness;            /* info["network_compactness"] */
+    double *network_compactness_difference; /* info["network_compactness_difference"] */
+} orlg_step_io;
+
+/* counters of one env, rmsa_env.py:84-87 + optical_network_env.py:35-38 */
+typedef struct orlg_counters {
+    int64_t services_processed, services_accepted;
+    int64_t episode_services_processed, episode_services_accepted;
+    int64_t bit_rate_requested, bit_rate_provisioned;
+    int64_t episode_bit_rate_requested, episode_bit_rate_provisioned;
+} orlg_counters;
+
+typedef struct orlg_request {
+    int32_t service_id, src, dst, bit_rate;
+    double arrival_time, holding_time;
+} orlg_request;
+
+typedef struct orlg_env orlg_env;
+
+int orlg_abi_version(void);
+const char *orlg_last_error(void);
+int orlg_device_count(void);
+
+/* RMSAEnv.__init__ + reset(only_episode_counters=False) (rmsa_env.py:29-220) for B envs;
+ * env i is seeded like random.Random(seeds ? seeds[i] : base_seed + i) (optical_network_env.py:266-271). */
+int orlg_create(const orlg_topology *topo, const orlg_rmsa_config *cfg, int32_t batch, const uint64_t *seeds,
+                uint64_t base_seed, int32_t device, orlg_env **out);
+int orlg_destroy(orlg_env *env);
+/* use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own */
+int orlg_set_stream(orlg_env *env, void *hip_stream);
+int orlg_synchronize(orlg_env *env);
+
+/* RMSAEnv.reset(only_episode_counters) (rmsa_env.py:343-457), all envs */
+int orlg_reset(orlg_env *env, int32_t only_episode_counters);
+
+/* n_steps x { action = policy(env); env.step(action); optionally env.reset() when done }
+ * (utils.py:134-149, rmsa_env.py:222-341).  policy EXTERNAL: actions is [B][2] int32 (path, initial_slot),
+ * n_steps must be 1; DEEPRMSA_EXTERNAL: actions is [B] int32.  auto_reset != 0 applies
+ * reset(only_episode_counters=True) to every env whose step returned done. */
+int orlg_step(orlg_env *env, int32_t policy, int32_t n_steps, const int32_t *actions, int32_t auto_reset,
+              const orlg_step_io *io);
+
+/* state read-back (all arrays [B] or [B][...] env-major) */
+int orlg_get_requests(orlg_env *env, orlg_request *out /* [B] */);
+int orlg_get_counters(orlg_env *env, orlg_counters *out /* [B] */);
+int orlg_get_current_time(orlg_env *env, double *out /* [B] */);
+/* topology.graph["available_slots"] as a bitmap: [B][E][W] uint64, bit s of word w = slot 64w+s free */
+int orlg_get_occupancy(orlg_env *env, uint64_t *out);
+int orlg_words_per_link(orlg_env *env);
+/* per-link time-weighted stats [B][E] each (rmsa_env.py:562-641); any pointer may be NULL */
+int orlg_get_link_stats(orlg_env *env, double *utilization, double *external_fragmentation, double *compactness,
+                        double *last_update);
+/* topology.graph["throughput"|"compactness"|"last_update"] [B] each */
+int orlg_get_graph_stats(orlg_env *env, double *throughput, double *compactness, double *last_update);
+/* bit-rate histograms [B][num_bit_rates] int64 each: requested, provisioned, episode requested, episode provisioned */
+int orlg_get_bit_rate_hist(orlg_env *env, int64_t *req, int64_t *prov, int64_t *ereq, int64_t *eprov);
+int orlg_get_num_running(orlg_env *env, int32_t *out /* [B] */);
+int orlg_get_episodes_done(orlg_env *env, int64_t *out /* [B] */);
+
+/* heuristic-callback queries for ONE env (rmsa_env.py:721-756, 774-804): for each of the k candidate
+ * paths of env_index's pending request, the AND of the free-slot bitmaps of its links.
+ * masks: [k][W] uint64 (host or device), nslots: [k] int32 = get_number_slots(path). */
+int orlg_query_path_masks(orlg_env *env, int32_t env_index, uint64_t *masks, int32_t *nslots);
+
+/* DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env: [B][1 + 2N + (2j+3)k] float64 */
+int orlg_deeprmsa_observation(orlg_env *env, double *out);
+int orlg_deeprmsa_obs_dim(orlg_env *env);
+
+/* sum of all B counter records + accepted/processed, for multi-GPU statistics: out[0..7] = orlg_counters summed,
+ * out[8] = total episodes done, out[9] = B.  The caller all-reduces this vector (RCCL, SUM). */
+int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */);
+
+/* host build of the device's natural-log routine (bit-identical algorithm; see csrc/orlg_math.h) */
+double orlg_host_log(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,662 @@
+// orlg_api.hip -- host side of liborlg.so: the C ABI declared in include/orlg.h.
+// Owns the device state of B environments, builds the read-only tables, seeds MT19937 the way
+// random.Random(int) does and launches the kernels of orlg_kernels.hip.  No CPU compute path exists:
+// every entry point that touches environments needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orlg.h"
+#include "orlg_kernels.hip"
+
+// ---------------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(ORLG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------- handle
+struct orlg_env {
+    OrlgParams p;
+    int W;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    size_t lds_block_bytes;
+    int num_paths;
+    // owned device buffers
+    std::vector<void *> bufs;
+    unsigned char *staging;
+    size_t staging_bytes;
+    // lazily grown io buffers
+    void *io_buf[12];
+    size_t io_cap[12];
+    int32_t *d_actions;
+    size_t d_actions_cap;
+};
+
+template <typename T>
+static int dev_alloc(orlg_env *e, T **out, size_t count) {
+    void *ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+    e->bufs.push_back(ptr);
+    *out = static_cast<T *>(ptr);
+    return ORLG_OK;
+}
+template <typename T>
+static int dev_upload(orlg_env *e, T **out, const T *host, size_t count) {
+    int rc = dev_alloc(e, out, count);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*out, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return ORLG_OK;
+}
+
+// ---------------------------------------------------------------------------------------- MT19937 seeding
+// CPython _randommodule.c: random.Random(n) -> init_by_array(32-bit little-endian chunks of abs(n)).
+static void mt_seed(uint32_t *mt, uint64_t seed) {
+    uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+    int len = key[1] ? 2 : 1;
+    mt[0] = 19650218u;
+    for (int i = 1; i < ORLG_MT_N; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int i = 1, j = 0;
+    for (int k = ORLG_MT_N > len ? ORLG_MT_N : len; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= ORLG_MT_N) { mt[0] = mt[ORLG_MT_N - 1]; i = 1; }
+        if (j >= len) j = 0;
+    }
+    for (int k = ORLG_MT_N - 1; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= ORLG_MT_N) { mt[0] = mt[ORLG_MT_N - 1]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+}
+
+// ---------------------------------------------------------------------------------------- small kernels
+// reset(only_episode_counters=False) state: every slot free, empty queue, zero counters and statistics;
+// the RNG state (mt, mt_idx) is deliberately kept (optical_network_env.py:216-264, rmsa_env.py:391-455).
+__global__ void orlg_clear_state_kernel(OrlgParams p, int W, int keep_rng) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < (size_t)p.B * p.NW; i += nth) p.occ[i] = valid_mask(p.S, (int)(i % W));
+    for (size_t i = tid; i < (size_t)p.B * p.Q; i += nth) {
+        p.qtime[i] = __longlong_as_double((long long)ORLG_INF_BITS);
+        p.qdesc[i] = 0;
+    }
+    for (size_t i = tid; i < (size_t)p.B * 4 * p.NBR; i += nth) p.hist[i] = 0;
+    for (size_t i = tid; i < (size_t)p.B * 4 * p.E; i += nth) p.lstat[i] = 0.0;
+    for (size_t i = tid; i < (size_t)p.B; i += nth) {
+        OrlgEnvScalars s;
+        memset(&s, 0, sizeof(s));
+        s.mt_idx = keep_rng ? p.scal[i].mt_idx : ORLG_MT_N;
+        p.scal[i] = s;
+    }
+}
+
+enum { EX_REQUEST, EX_COUNTERS, EX_TIME, EX_GRAPH, EX_RUNNING, EX_EPISODES, EX_HIST, EX_LSTAT };
+__global__ void orlg_extract_kernel(OrlgParams p, int what, unsigned char *out) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    const size_t B = p.B;
+    if (what == EX_REQUEST) {
+        orlg_request *o = reinterpret_cast<orlg_request *>(out);
+        for (size_t i = tid; i < B; i += nth) {
+            const OrlgEnvScalars &s = p.scal[i];
+            o[i].service_id = s.req_sid; o[i].src = s.req_src; o[i].dst = s.req_dst;
+            o[i].bit_rate = p.bit_rates[s.req_br];
+            o[i].arrival_time = s.req_arrival; o[i].holding_time = s.req_holding;
+        }
+    } else if (what == EX_COUNTERS) {
+        int64_t *o = reinterpret_cast<int64_t *>(out);
+        for (size_t i = tid; i < B * 8; i += nth) o[i] = p.scal[i / 8].c[i % 8];
+    } else if (what == EX_TIME) {
+        double *o = reinterpret_cast<double *>(out);
+        for (size_t i = tid; i < B; i += nth) o[i] = p.scal[i].current_time;
+    } else if (what == EX_GRAPH) {
+        double *o = reinterpret_cast<double *>(out);
+        for (size_t i = tid; i < B; i += nth) {
+            o[i] = p.scal[i].g_throughput; o[B + i] = p.scal[i].g_compactness; o[2 * B + i] = p.scal[i].g_last_update;
+        }
+    } else if (what == EX_RUNNING) {
+        int32_t *o = reinterpret_cast<int32_t *>(out);
+        for (size_t i = tid; i < B; i += nth) o[i] = p.scal[i].n_running;
+    } else if (what == EX_EPISODES) {
+        int64_t *o = reinterpret_cast<int64_t *>(out);
+        for (size_t i = tid; i < B; i += nth) o[i] = p.scal[i].episodes_done;
+    } else if (what == EX_HIST) {  // [4][B][NBR] int64 from [B][4][NBR] int32
+        int64_t *o = reinterpret_cast<int64_t *>(out);
+        const size_t n = (size_t)p.NBR;
+        for (size_t i = tid; i < 4 * B * n; i += nth) {
+            size_t k = i / (B * n), r = i % (B * n), b = r / n, q = r % n;
+            o[i] = p.hist[(b * 4 + k) * n + q];
+        }
+    } else if (what == EX_LSTAT) {  // [4][B][E] from [B][4][E]
+        double *o = reinterpret_cast<double *>(out);
+        const size_t n = (size_t)p.E;
+        for (size_t i = tid; i < 4 * B * n; i += nth) {
+            size_t k = i / (B * n), r = i % (B * n), b = r / n, q = r % n;
+            o[i] = p.lstat[(b * 4 + k) * n + q];
+        }
+    }
+}
+
+__global__ void orlg_overflow_kernel(const OrlgEnvScalars *scal, int B, int *out) {
+    int any = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) any |= scal[i].q_overflow;
+    if (any) atomicOr(out, 1);
+}
+
+// ---------------------------------------------------------------------------------------- kernel dispatch
+typedef void (*rmsa_kernel_t)(const OrlgParams);
+template <int W>
+static rmsa_kernel_t pick_stats(int stats) {
+    switch (stats) {
+        case 0: return orlg_rmsa_kernel<W, 0>;
+        case 1: return orlg_rmsa_kernel<W, 1>;
+        default: return orlg_rmsa_kernel<W, 2>;
+    }
+}
+static rmsa_kernel_t pick_rmsa(int W, int stats) {
+    switch (W) {
+        case 1: return pick_stats<1>(stats);
+        case 2: return pick_stats<2>(stats);
+        case 3: return pick_stats<3>(stats);
+        case 4: return pick_stats<4>(stats);
+        case 5: return pick_stats<5>(stats);
+        case 6: return pick_stats<6>(stats);
+        case 8: return pick_stats<8>(stats);
+        default: return nullptr;
+    }
+}
+static rmsa_kernel_t pick_obs(int W) {
+    switch (W) {
+        case 1: return orlg_deeprmsa_obs_kernel<1>;
+        case 2: return orlg_deeprmsa_obs_kernel<2>;
+        case 3: return orlg_deeprmsa_obs_kernel<3>;
+        case 4: return orlg_deeprmsa_obs_kernel<4>;
+        case 5: return orlg_deeprmsa_obs_kernel<5>;
+        case 6: return orlg_deeprmsa_obs_kernel<6>;
+        case 8: return orlg_deeprmsa_obs_kernel<8>;
+        default: return nullptr;
+    }
+}
+typedef void (*masks_kernel_t)(const OrlgParams, int, u64 *, int32_t *);
+static masks_kernel_t pick_masks(int W) {
+    switch (W) {
+        case 1: return orlg_path_masks_kernel<1>;
+        case 2: return orlg_path_masks_kernel<2>;
+        case 3: return orlg_path_masks_kernel<3>;
+        case 4: return orlg_path_masks_kernel<4>;
+        case 5: return orlg_path_masks_kernel<5>;
+        case 6: return orlg_path_masks_kernel<6>;
+        case 8: return orlg_path_masks_kernel<8>;
+        default: return nullptr;
+    }
+}
+
+static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
+    rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level);
+    if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)e->lds_block_bytes));
+    dim3 grid((p.B + ORLG_WAVES_PER_BLOCK - 1) / ORLG_WAVES_PER_BLOCK), block(ORLG_WAVE * ORLG_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, p);
+    HIP_TRY(hipGetLastError());
+    return ORLG_OK;
+}
+
+static int is_device_ptr(const void *ptr) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// copy `bytes` from a device buffer to a caller pointer (host or device) and wait
+static int copy_out(orlg_env *e, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+static int ensure_staging(orlg_env *e, size_t bytes) {
+    if (bytes <= e->staging_bytes) return ORLG_OK;
+    if (e->staging) HIP_TRY(hipFree(e->staging));
+    e->staging = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->staging), bytes));
+    e->staging_bytes = bytes;
+    return ORLG_OK;
+}
+
+static int extract(orlg_env *e, int what, size_t bytes) {
+    int rc = ensure_staging(e, bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(orlg_extract_kernel, dim3(256), dim3(256), 0, e->stream, e->p, what, e->staging);
+    HIP_TRY(hipGetLastError());
+    return ORLG_OK;
+}
+
+// ---------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int orlg_abi_version(void) { return ORLG_ABI_VERSION; }
+const char *orlg_last_error(void) { return g_err.c_str(); }
+double orlg_host_log(double x) { return orlg_log(x); }
+
+int orlg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int orlg_destroy(orlg_env *e) {
+    if (!e) return ORLG_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (void *b : e->bufs) (void)hipFree(b);
+    if (e->staging) (void)hipFree(e->staging);
+    for (int i = 0; i < 12; i++)
+        if (e->io_buf[i]) (void)hipFree(e->io_buf[i]);
+    if (e->d_actions) (void)hipFree(e->d_actions);
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ORLG_OK;
+}
+
+int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch, const uint64_t *seeds,
+                uint64_t base_seed, int32_t device, orlg_env **out) {
+    if (!t || !c || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int N = t->num_nodes, E = t->num_links, K = t->k_paths, S = c->num_slots, NBR = c->num_bit_rates;
+    if (batch < 1) return fail(ORLG_ERR_INVALID, "batch must be >= 1");
+    if (N < 2 || N > 64) return fail(ORLG_ERR_INVALID, "num_nodes %d not in 2..64", N);
+    if (E < 1 || E > 255) return fail(ORLG_ERR_INVALID, "num_links %d not in 1..255", E);
+    if (S < 1 || S > 512) return fail(ORLG_ERR_INVALID, "num_slots %d not in 1..512", S);
+    if (NBR < 1 || NBR > 64) return fail(ORLG_ERR_INVALID, "num_bit_rates %d not in 1..64", NBR);
+    if (t->num_paths < 1 || t->num_paths >= (1 << 14)) return fail(ORLG_ERR_INVALID, "num_paths %d not in 1..16383", t->num_paths);
+    int W = (S + 63) / 64;
+    if (W == 7) W = 8;  // no W=7 instantiation: pad to 8 words (top word all invalid)
+    if (K < 1 || K * W > 64) return fail(ORLG_ERR_INVALID, "k_paths * words_per_link = %d exceeds one wavefront", K * W);
+    if (c->j < 1 || c->j > 16) return fail(ORLG_ERR_INVALID, "j %d not in 1..16", c->j);
+    if (!(c->arrival_lambda > 0) || !(c->holding_lambda > 0) || !(c->channel_width > 0))
+        return fail(ORLG_ERR_INVALID, "arrival_lambda, holding_lambda and channel_width must be positive");
+    if (c->stats_level < 0 || c->stats_level > 2) return fail(ORLG_ERR_INVALID, "bad stats_level");
+    for (int i = 0; i < N * N; i++) {
+        int s = i / N, d = i % N;
+        if (s != d && (t->pair_path_count[i] != K || t->pair_path_base[i] < 0 || t->pair_path_base[i] + K > t->num_paths))
+            return fail(ORLG_ERR_INVALID, "pair (%d,%d) does not have k=%d path records", s, d, K);
+    }
+    int ndev = orlg_device_count();
+    if (ndev < 1) return fail(ORLG_ERR_NO_DEVICE, "no HIP device visible: liborlg has no CPU path");
+    if (device < 0 || device >= ndev) return fail(ORLG_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    orlg_env *e = new orlg_env();
+    memset(&e->p, 0, sizeof(e->p));
+    e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
+    e->d_actions = nullptr; e->d_actions_cap = 0; e->num_paths = t->num_paths;
+    for (int i = 0; i < 12; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
+
+    OrlgParams &p = e->p;
+    p.B = batch; p.N = N; p.E = E; p.S = S; p.K = K; p.NBR = NBR; p.NW = E * W;
+    p.episode_length = c->episode_length; p.reward_mode = c->reward_mode; p.stats_level = c->stats_level; p.j = c->j;
+    p.obs_dim = 1 + 2 * N + (2 * c->j + 3) * K;
+    p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
+    // release-queue capacity: offered load in Erlang = arrival_lambda / holding_lambda; the number of
+    // services in progress is at most Poisson(load) distributed -> mean + 8 sigma + slack, whole waves
+    int Q = c->queue_capacity;
+    if (Q <= 0) {
+        double load = c->arrival_lambda / c->holding_lambda;
+        Q = (int)(load + 8.0 * std::sqrt(load) + 32.0);
+    }
+    Q = ((Q + 63) / 64) * 64;
+    if (Q > 4096) { orlg_destroy(e); return fail(ORLG_ERR_INVALID, "queue_capacity %d too large for LDS (max 4096)", Q); }
+    p.Q = Q;
+
+    // per-wave LDS layout
+    auto up16 = [](int v) { return (v + 15) & ~15; };
+    int off = 0;
+    p.l_occ = off; off = up16(off + p.NW * 8);
+    p.l_qtime = off; off = up16(off + Q * 8);
+    p.l_qdesc = off; off = up16(off + Q * 4);
+    p.l_mt = off; off = up16(off + ORLG_MT_N * 4);
+    p.l_lstat = off; off = up16(off + 4 * E * 8);
+    p.l_hist = off; off = up16(off + 4 * NBR * 4);
+    p.l_lint = off; off = up16(off + E * 4);
+    p.l_scratch = off; off = up16(off + 64 * 16);
+    p.l_wave_bytes = off;
+    e->lds_block_bytes = (size_t)off * ORLG_WAVES_PER_BLOCK;
+    if (e->lds_block_bytes > 160 * 1024) {
+        orlg_destroy(e);
+        return fail(ORLG_ERR_INVALID, "environment state (%zu B per workgroup) exceeds the 160 KiB LDS", e->lds_block_bytes);
+    }
+
+    int rc = ORLG_OK;
+#define TRY(x) do { rc = (x); if (rc) { orlg_destroy(e); return rc; } } while (0)
+    // read-only tables
+    {
+        std::vector<OrlgPathRec> recs(t->num_paths);
+        for (int g = 0; g < t->num_paths; g++) {
+            memset(&recs[g], 0, sizeof(OrlgPathRec));
+            int h = t->path_hops[g], se = t->path_se[g];
+            if (h < 1 || h > ORLG_MAX_HOPS || t->path_link_off[g + 1] - t->path_link_off[g] != h) {
+                orlg_destroy(e);
+                return fail(ORLG_ERR_INVALID, "path %d: hops %d not in 1..%d or CSR mismatch", g, h, ORLG_MAX_HOPS);
+            }
+            if (se < 1 || se >= ORLG_NSLOT_STRIDE) { orlg_destroy(e); return fail(ORLG_ERR_INVALID, "path %d: spectral efficiency %d not in 1..7", g, se); }
+            recs[g].hops = (uint8_t)h; recs[g].se = (uint8_t)se;
+            for (int i = 0; i < h; i++) {
+                int l = t->path_links[t->path_link_off[g] + i];
+                if (l < 0 || l >= E) { orlg_destroy(e); return fail(ORLG_ERR_INVALID, "path %d: link %d out of range", g, l); }
+                recs[g].link[i] = (uint8_t)l;
+            }
+        }
+        OrlgPathRec *d_recs; TRY(dev_upload(e, &d_recs, recs.data(), recs.size())); p.recs = d_recs;
+        // get_number_slots (rmsa_env.py:708-719): ceil(bit_rate / (SE * channel_width)) + 1
+        std::vector<uint16_t> ns((size_t)NBR * ORLG_NSLOT_STRIDE, 0);
+        for (int b = 0; b < NBR; b++)
+            for (int se = 1; se < ORLG_NSLOT_STRIDE; se++) {
+                double q = (double)c->bit_rates[b] / ((double)se * c->channel_width);
+                double n = std::ceil(q) + 1;
+                ns[(size_t)b * ORLG_NSLOT_STRIDE + se] = (uint16_t)(n > 65535 ? 65535 : n);
+            }
+        uint16_t *d_ns; TRY(dev_upload(e, &d_ns, ns.data(), ns.size())); p.nslots_tab = d_ns;
+        int32_t *d_i; double *d_d;
+        TRY(dev_upload(e, &d_i, t->pair_path_base, (size_t)N * N)); p.pair_base = d_i;
+        TRY(dev_upload(e, &d_i, c->bit_rates, (size_t)NBR)); p.bit_rates = d_i;
+        TRY(dev_upload(e, &d_d, c->bit_rate_cum, (size_t)NBR)); p.br_cum = d_d;
+        TRY(dev_upload(e, &d_d, c->src_cum, (size_t)N)); p.src_cum = d_d;
+        TRY(dev_upload(e, &d_d, c->dst_cum, (size_t)N * N)); p.dst_cum = d_d;
+    }
+    // per-env state
+    TRY(dev_alloc(e, &p.occ, (size_t)batch * p.NW));
+    TRY(dev_alloc(e, &p.qtime, (size_t)batch * Q));
+    TRY(dev_alloc(e, &p.qdesc, (size_t)batch * Q));
+    TRY(dev_alloc(e, &p.mt, (size_t)batch * ORLG_MT_N));
+    TRY(dev_alloc(e, &p.scal, (size_t)batch));
+    TRY(dev_alloc(e, &p.hist, (size_t)batch * 4 * NBR));
+    TRY(dev_alloc(e, &p.lstat, (size_t)batch * 4 * E));
+    {
+        std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
+        for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+        hipError_t er = hipMemcpy(p.mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (er != hipSuccess) { orlg_destroy(e); return fail(ORLG_ERR_HIP, "upload of MT19937 states: %s", hipGetErrorString(er)); }
+    }
+    hipLaunchKernelGGL(orlg_clear_state_kernel, dim3(512), dim3(256), 0, e->stream, p, W, 0);
+    OrlgParams pi = p;
+    pi.mode = ORLG_MODE_INIT; pi.n_steps = 1;
+    TRY(launch_rmsa(e, pi));
+    {
+        hipError_t er = hipStreamSynchronize(e->stream);
+        if (er != hipSuccess) { orlg_destroy(e); return fail(ORLG_ERR_HIP, "initial reset: %s", hipGetErrorString(er)); }
+    }
+#undef TRY
+    *out = e;
+    return ORLG_OK;
+}
+
+int orlg_set_stream(orlg_env *e, void *hip_stream) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
+    if (hip_stream) {
+        e->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    return ORLG_OK;
+}
+
+int orlg_synchronize(orlg_env *e) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+int orlg_reset(orlg_env *e, int32_t only_episode_counters) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    OrlgParams p = e->p;
+    p.n_steps = 1;
+    if (only_episode_counters) {
+        p.mode = ORLG_MODE_EPISODE_RESET;
+    } else {
+        hipLaunchKernelGGL(orlg_clear_state_kernel, dim3(512), dim3(256), 0, e->stream, e->p, e->W, 1);
+        HIP_TRY(hipGetLastError());
+        p.mode = ORLG_MODE_INIT;
+    }
+    return launch_rmsa(e, p);
+}
+
+// io slot ids
+enum { IO_PATH, IO_SLOT, IO_ACC, IO_DONE, IO_REWARD, IO_REQ, IO_ARR, IO_HOLD, IO_COMP, IO_CDIFF };
+
+int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actions, int32_t auto_reset,
+              const orlg_step_io *io) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    if (n_steps < 1) return fail(ORLG_ERR_INVALID, "n_steps must be >= 1");
+    if (policy < ORLG_POLICY_EXTERNAL || policy > ORLG_POLICY_DEEPRMSA_EXTERNAL) return fail(ORLG_ERR_INVALID, "unknown policy %d", policy);
+    const bool ext = policy == ORLG_POLICY_EXTERNAL || policy == ORLG_POLICY_DEEPRMSA_EXTERNAL;
+    if (ext && (!actions || n_steps != 1)) return fail(ORLG_ERR_INVALID, "external actions need an action array and n_steps == 1");
+    HIP_TRY(hipSetDevice(e->device));
+    OrlgParams p = e->p;
+    p.mode = ORLG_MODE_STEP; p.n_steps = n_steps; p.policy = policy; p.auto_reset = auto_reset;
+    if (ext) {
+        size_t n = (size_t)p.B * (policy == ORLG_POLICY_EXTERNAL ? 2 : 1);
+        if (is_device_ptr(actions)) {
+            p.actions = actions;
+        } else {
+            if (n > e->d_actions_cap) {
+                if (e->d_actions) HIP_TRY(hipFree(e->d_actions));
+                e->d_actions = nullptr;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_actions), n * sizeof(int32_t)));
+                e->d_actions_cap = n;
+            }
+            HIP_TRY(hipMemcpyAsync(e->d_actions, actions, n * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+            p.actions = e->d_actions;
+        }
+    }
+    // outputs: write straight into device pointers, stage host pointers
+    struct Slot { void *user; size_t elem; void **kptr; };
+    const size_t cnt = (size_t)n_steps * p.B;
+    Slot slots[10] = {
+        {io ? io->act_path : nullptr, 4, (void **)&p.o_path},       {io ? io->act_slot : nullptr, 4, (void **)&p.o_slot},
+        {io ? io->accepted : nullptr, 1, (void **)&p.o_accepted},   {io ? io->done : nullptr, 1, (void **)&p.o_done},
+        {io ? io->reward : nullptr, 8, (void **)&p.o_reward},       {io ? io->request : nullptr, 16, (void **)&p.o_request},
+        {io ? io->arrival : nullptr, 8, (void **)&p.o_arrival},     {io ? io->holding : nullptr, 8, (void **)&p.o_holding},
+        {io ? io->network_compactness : nullptr, 8, (void **)&p.o_compact},
+        {io ? io->network_compactness_difference : nullptr, 8, (void **)&p.o_compact_diff}};
+    bool staged[10] = {false};
+    for (int i = 0; i < 10; i++) {
+        *slots[i].kptr = nullptr;
+        if (!slots[i].user) continue;
+        if (is_device_ptr(slots[i].user)) {
+            *slots[i].kptr = slots[i].user;
+        } else {
+            size_t bytes = cnt * slots[i].elem;
+            if (bytes > e->io_cap[i]) {
+                if (e->io_buf[i]) HIP_TRY(hipFree(e->io_buf[i]));
+                e->io_buf[i] = nullptr; e->io_cap[i] = 0;
+                HIP_TRY(hipMalloc(&e->io_buf[i], bytes));
+                e->io_cap[i] = bytes;
+            }
+            *slots[i].kptr = e->io_buf[i];
+            staged[i] = true;
+        }
+    }
+    int rc = launch_rmsa(e, p);
+    if (rc) return rc;
+    bool any = false;
+    for (int i = 0; i < 10; i++)
+        if (staged[i]) {
+            HIP_TRY(hipMemcpyAsync(slots[i].user, e->io_buf[i], cnt * slots[i].elem, hipMemcpyDeviceToHost, e->stream));
+            any = true;
+        }
+    if (any) HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+int orlg_get_requests(orlg_env *e, orlg_request *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t bytes = (size_t)e->p.B * sizeof(orlg_request);
+    int rc = extract(e, EX_REQUEST, bytes);
+    return rc ? rc : copy_out(e, out, e->staging, bytes);
+}
+int orlg_get_counters(orlg_env *e, orlg_counters *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t bytes = (size_t)e->p.B * sizeof(orlg_counters);
+    int rc = extract(e, EX_COUNTERS, bytes);
+    return rc ? rc : copy_out(e, out, e->staging, bytes);
+}
+int orlg_get_current_time(orlg_env *e, double *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t bytes = (size_t)e->p.B * 8;
+    int rc = extract(e, EX_TIME, bytes);
+    return rc ? rc : copy_out(e, out, e->staging, bytes);
+}
+int orlg_words_per_link(orlg_env *e) { return e ? e->W : ORLG_ERR_INVALID; }
+int orlg_get_occupancy(orlg_env *e, uint64_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return copy_out(e, out, e->p.occ, (size_t)e->p.B * e->p.NW * 8);
+}
+int orlg_get_link_stats(orlg_env *e, double *u, double *f, double *c, double *t) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t one = (size_t)e->p.B * e->p.E * 8;
+    int rc = extract(e, EX_LSTAT, 4 * one);
+    if (rc) return rc;
+    double *outs[4] = {u, f, c, t};
+    for (int k = 0; k < 4; k++)
+        if (outs[k]) HIP_TRY(hipMemcpyAsync(outs[k], e->staging + k * one, one, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+int orlg_get_graph_stats(orlg_env *e, double *thr, double *comp, double *lu) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t one = (size_t)e->p.B * 8;
+    int rc = extract(e, EX_GRAPH, 3 * one);
+    if (rc) return rc;
+    double *outs[3] = {thr, comp, lu};
+    for (int k = 0; k < 3; k++)
+        if (outs[k]) HIP_TRY(hipMemcpyAsync(outs[k], e->staging + k * one, one, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+int orlg_get_bit_rate_hist(orlg_env *e, int64_t *req, int64_t *prov, int64_t *ereq, int64_t *eprov) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t one = (size_t)e->p.B * e->p.NBR * 8;
+    int rc = extract(e, EX_HIST, 4 * one);
+    if (rc) return rc;
+    int64_t *outs[4] = {req, prov, ereq, eprov};
+    for (int k = 0; k < 4; k++)
+        if (outs[k]) HIP_TRY(hipMemcpyAsync(outs[k], e->staging + k * one, one, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+int orlg_get_num_running(orlg_env *e, int32_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t bytes = (size_t)e->p.B * 4;
+    int rc = extract(e, EX_RUNNING, bytes);
+    return rc ? rc : copy_out(e, out, e->staging, bytes);
+}
+int orlg_get_episodes_done(orlg_env *e, int64_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t bytes = (size_t)e->p.B * 8;
+    int rc = extract(e, EX_EPISODES, bytes);
+    return rc ? rc : copy_out(e, out, e->staging, bytes);
+}
+
+int orlg_query_path_masks(orlg_env *e, int32_t env_index, uint64_t *masks, int32_t *nslots) {
+    if (!e || !masks || !nslots) return fail(ORLG_ERR_INVALID, "null argument");
+    if (env_index < 0 || env_index >= e->p.B) return fail(ORLG_ERR_INVALID, "env_index out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    size_t mbytes = (size_t)e->p.K * e->W * 8, nbytes = (size_t)e->p.K * 4;
+    int rc = ensure_staging(e, mbytes + nbytes + 64);
+    if (rc) return rc;
+    masks_kernel_t k = pick_masks(e->W);
+    u64 *dm = reinterpret_cast<u64 *>(e->staging);
+    int32_t *dn = reinterpret_cast<int32_t *>(e->staging + ((mbytes + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(k, dim3(1), dim3(ORLG_WAVE), (size_t)e->p.NW * 8, e->stream, e->p, env_index, dm, dn);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(masks, dm, mbytes, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipMemcpyAsync(nslots, dn, nbytes, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+int orlg_deeprmsa_obs_dim(orlg_env *e) { return e ? e->p.obs_dim : ORLG_ERR_INVALID; }
+int orlg_deeprmsa_observation(orlg_env *e, double *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    OrlgParams p = e->p;
+    size_t bytes = (size_t)p.B * p.obs_dim * 8;
+    const bool dev = is_device_ptr(out);
+    if (!dev) {
+        int rc = ensure_staging(e, bytes);
+        if (rc) return rc;
+        p.o_obs = reinterpret_cast<double *>(e->staging);
+    } else {
+        p.o_obs = out;
+    }
+    rmsa_kernel_t k = pick_obs(e->W);
+    size_t lds = (size_t)(((p.NW * 8 + 15) & ~15)) * ORLG_WAVES_PER_BLOCK;
+    dim3 grid((p.B + ORLG_WAVES_PER_BLOCK - 1) / ORLG_WAVES_PER_BLOCK), block(ORLG_WAVE * ORLG_WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k, grid, block, lds, e->stream, p);
+    HIP_TRY(hipGetLastError());
+    if (!dev) return copy_out(e, out, e->staging, bytes);
+    return ORLG_OK;
+}
+
+int orlg_reduce_counters(orlg_env *e, int64_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_staging(e, 16 * 8 + 16);
+    if (rc) return rc;
+    long long *d = reinterpret_cast<long long *>(e->staging);
+    int *flag = reinterpret_cast<int *>(e->staging + 16 * 8);
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, e->stream));
+    hipLaunchKernelGGL(orlg_reduce_counters_kernel, dim3(1), dim3(256), 0, e->stream, e->p.scal, e->p.B, d);
+    hipLaunchKernelGGL(orlg_overflow_kernel, dim3(64), dim3(256), 0, e->stream, e->p.scal, e->p.B, flag);
+    HIP_TRY(hipGetLastError());
+    int hflag = 0;
+    HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out, d, 16 * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (hflag) return fail(ORLG_ERR_QUEUE_FULL, "a release queue overflowed (capacity %d): raise queue_capacity", e->p.Q);
+    return ORLG_OK;
+}
+
+}  // extern "C"

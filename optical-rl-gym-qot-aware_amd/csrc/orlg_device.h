@@ -1,0 +1,73 @@
+// orlg_device.h -- device-side data layout shared by the kernels (orlg_kernels.hip) and the host API
+// (orlg_api.hip).  Names follow the reference's domain: links, slots, paths, services, release queue.
+#pragma once
+#include <stdint.h>
+
+#define ORLG_WAVE 64
+#define ORLG_WAVES_PER_BLOCK 4
+#define ORLG_MT_N 624
+#define ORLG_MT_M 397
+#define ORLG_MAX_W 8          // 64-bit words per link: S <= 512
+#define ORLG_MAX_HOPS 14
+#define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
+
+// One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
+// "index" of every hop (utils.py:27-36, rmsa_env.py:479-483).
+struct __attribute__((aligned(16))) OrlgPathRec {
+    uint8_t hops, se;
+    uint8_t link[ORLG_MAX_HOPS];
+};
+
+// Per-environment scalars kept in HBM between launches (one record per env, 256 B).
+struct __attribute__((aligned(16))) OrlgEnvScalars {
+    double current_time;                                   // optical_network_env.py:33
+    double req_arrival, req_holding;                       // current_service.arrival_time / holding_time
+    double g_throughput, g_compactness, g_last_update;     // topology.graph[...] rmsa_env.py:537-560
+    int64_t c[8];                                          // orlg_counters order
+    int64_t sum_bitrate_running;                           // sum of bit_rate over running services
+    int64_t episodes_done;
+    int32_t sum_slots_hops;                                // sum of number_slots * hops over running services
+    int32_t n_running;
+    int32_t req_src, req_dst, req_br, req_sid;             // pending request (br = bit-rate INDEX)
+    int32_t mt_idx;                                        // MT19937 position (0..624)
+    int32_t new_service;                                   // self._new_service
+    int32_t q_overflow;                                    // release queue overflowed (error)
+    int32_t pad[5];
+};
+static_assert(sizeof(OrlgEnvScalars) == 192, "OrlgEnvScalars layout");
+
+enum { ORLG_MODE_STEP = 0, ORLG_MODE_INIT = 1, ORLG_MODE_EPISODE_RESET = 2 };
+// device-side policy ids (== include/orlg.h ORLG_POLICY_*)
+enum { ORLG_POLICY_EXT = -1, ORLG_POLICY_SP = 0, ORLG_POLICY_SAP = 1, ORLG_POLICY_LLP = 2, ORLG_POLICY_DEEP_SP = 3,
+       ORLG_POLICY_DEEP_SAP = 4, ORLG_POLICY_DEEP_EXT = 5 };
+
+// Kernel parameters (passed by value).
+struct OrlgParams {
+    // sizes
+    int32_t B, N, E, S, K, NBR, Q, NW;       // NW = E*W words of occupancy per env
+    int32_t episode_length, n_steps, policy, auto_reset, mode, reward_mode, stats_level, j;
+    int32_t obs_dim, pad0;
+    double arrival_lambda, holding_lambda;
+    // per-env state in HBM
+    uint64_t *occ;            // [B][NW]   free-slot bitmap, word (link*W + w)
+    double *qtime;            // [B][Q]    release time, +inf = empty slot
+    uint32_t *qdesc;          // [B][Q]    path gid | start << 14 | bit-rate index << 24
+    uint32_t *mt;             // [B][624]
+    OrlgEnvScalars *scal;     // [B]
+    int32_t *hist;            // [B][4][NBR] requested, provisioned, episode requested, episode provisioned
+    double *lstat;            // [B][4][E] utilization, external_fragmentation, compactness, last_update
+    // read-only tables (shared by all envs)
+    const int32_t *pair_base;       // [N*N]
+    const OrlgPathRec *recs;        // [num_paths]
+    const uint16_t *nslots_tab;     // [NBR][8]
+    const int32_t *bit_rates;       // [NBR]
+    const double *br_cum, *src_cum, *dst_cum;
+    // per-call IO
+    const int32_t *actions;
+    int32_t *o_path, *o_slot, *o_request;
+    uint8_t *o_accepted, *o_done;
+    double *o_reward, *o_arrival, *o_holding, *o_compact, *o_compact_diff;
+    double *o_obs;
+    // per-wave LDS layout (byte offsets from the wave's base) and size
+    int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wave_bytes, pad1;
+};

@@ -13,7 +13,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_BIT_RATES = 64
 
-POLICY = {"sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4, "external": -1}
+POLICY = {"sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4, "external": -1,
+          "deeprmsa_external": 5}
 
 
 class Topology(C.Structure):
@@ -107,6 +108,7 @@ def lib(asan=False):
         L.orc_get_available_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.POINTER(Trace)]
         L.orc_py_random_stream.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+        L.orc_set_log_fn.argtypes = [C.c_void_p]
         _LIB[asan] = L
     return _LIB[asan]
 
@@ -253,6 +255,11 @@ class OracleEnv:
             ap = _ptr(actions)
         self.L.orc_run(self.h, POLICY[policy], int(n_steps), 1 if reset_on_done else 0, ap, C.byref(tr))
         return out
+
+
+def set_log_fn(fn_ptr, asan=False):
+    """Use another natural log in expovariate (a C function pointer as int / c_void_p); None = libm."""
+    lib(asan).orc_set_log_fn(C.c_void_p(fn_ptr) if fn_ptr else None)
 
 
 def py_random_stream(seed, n):

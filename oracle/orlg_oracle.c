@@ -85,8 +85,12 @@ static double py_random(py_rng *r) {
     return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
 }
 
-/* Lib/random.py expovariate: -log(1.0 - random()) / lambd */
-static double py_expovariate(py_rng *r, double lambd) { return -log(1.0 - py_random(r)) / lambd; }
+/* Lib/random.py expovariate: -log(1.0 - random()) / lambd.  Python takes log from the platform libm;
+ * orc_set_log_fn() lets a test substitute another log (the product's host build of its device log) so
+ * that the oracle and the device can be compared bit for bit on every float as well. */
+static double (*g_log)(double) = log;
+void orc_set_log_fn(double (*fn)(double)) { g_log = fn ? fn : log; }
+static double py_expovariate(py_rng *r, double lambd) { return -g_log(1.0 - py_random(r)) / lambd; }
 
 /* Lib/random.py choices(k=1) with cumulative weights: bisect_right(cum, random()*total, 0, n-1) */
 static int py_choice_cum(py_rng *r, const double *cum, int n) {
@@ -164,6 +168,7 @@ struct orc_env {
     event *heap;
     int n_heap, cap_heap;
     int64_t seq;
+    int last_path, last_slot; /* the [path, initial_slot] RMSAEnv.step last received */
     /* scratch for rle */
     int *r_start, *r_len;
     uint8_t *r_val;
@@ -509,6 +514,7 @@ void orc_get_request(const orc_env *e, orc_request *o) {
 void orc_step(orc_env *e, int path, int initial_slot, orc_step_result *out) {
     service *s = e->current;
     double previous = network_compactness(e);
+    e->last_path = path; e->last_slot = initial_slot;
     s->accepted = 0;
     if (path < e->K && initial_slot < e->S && path >= 0 && initial_slot >= 0) {
         int gid = path_gid(e, s->src, s->dst, path);
@@ -697,12 +703,15 @@ void orc_run(orc_env *e, int policy, int64_t n_steps, int reset_on_done, const i
             if (tr->arrival) tr->arrival[i] = s->arrival_time;
             if (tr->holding) tr->holding[i] = s->holding_time;
         }
-        if (policy < 0) { path = actions_in[2 * i]; slot = actions_in[2 * i + 1]; }
+        if (policy == ORC_POLICY_DEEPRMSA_EXTERNAL) { path = actions_in[i]; slot = 0; }
+        else if (policy < 0) { path = actions_in[2 * i]; slot = actions_in[2 * i + 1]; }
         else orc_policy(e, policy, &path, &slot);
-        if (policy == ORC_POLICY_DEEPRMSA_SP_FF || policy == ORC_POLICY_DEEPRMSA_SAP_FF)
+        if (policy == ORC_POLICY_DEEPRMSA_SP_FF || policy == ORC_POLICY_DEEPRMSA_SAP_FF || policy == ORC_POLICY_DEEPRMSA_EXTERNAL) {
             orc_step_deeprmsa(e, path, &r);
-        else
+            path = e->last_path; slot = e->last_slot; /* record the RMSA-level action */
+        } else {
             orc_step(e, path, slot, &r);
+        }
         if (tr) {
             if (tr->act_path) tr->act_path[i] = path;
             if (tr->act_slot) tr->act_slot[i] = slot;
