@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- env steps/s of the batched RMSA step() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chunk T] [--stats full|network|counters]
+
+One "step" = every environment of the batch advances by one RMSAEnv.step (policy -> provision ->
+release -> next arrival, all statistics) -- K steps are executed as ceil(K / chunk) launches of the
+persistent step kernel (chunk env-steps per launch).  Workload at N=1: BASELINE.json configs[1]
+(RMSA-v0, NSFNET, 320 slots, load 50, B = 4096 envs per GPU, shortest-available-path first-fit run on
+the device, seeds 10 + i).  Inputs are synthetic (the reference's own Poisson traffic generator run on
+the device) and all state is resident in HBM before the timed region starts.
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run; envs shard across ranks
+with no data-path communication ("weak" scaling: B per GPU fixed); the only collective is the RCCL
+all-reduce of the episode statistics vector at the end (orlg_reduce_counters).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ENV_KW = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000)
+TOPOLOGY = "nsfnet_chen_5-paths_6-modulations"
+
+
+def algorithmic_bytes_per_env_step(topo, W):
+    """read the env's occupancy once + RMW on provision and release over the mean
+    hop count + service record + request record + action/reward/done."""
+    import numpy as np
+    E = topo.num_links
+    hbar = float(np.mean(topo.path_hops))
+    return E * W * 8 + 2 * 2 * hbar * W * 8 + 48 + 40 + 16
+
+
+def cpu_baseline(topo, seconds=12.0):
+    """The CPU oracle (plain C restatement of the reference algorithm) on ONE host core, same workload,
+    bounded sample."""
+    from conftest import oracle_env_from_kwargs
+    kw = dict(ENV_KW, seed=10)
+    o = oracle_env_from_kwargs(topo, kw)
+    o.run("sap_ff", 500, fields=[])  # warm-up to steady state
+    n, done, t0 = 20000, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        o.run("sap_ff", n, fields=[])
+        done += n
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": done / dt, "unit": "env steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 env x {done} steps, SAP-FF, same NSFNET-320 load-50 workload, oracle/orlg_oracle.c"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--chunk", type=int, default=250, help="env steps per kernel launch")
+    ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
+    ap.add_argument("--policy", default="sap_ff")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    from conftest import load_topology
+    from optical_rl_gym_amd import BatchedRMSAEnv
+
+    topo = load_topology(TOPOLOGY)
+    B = args.batch
+    env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=10 + rank * B, stats_level=args.stats, device=local_rank)
+    # a dedicated (non-default) stream: the step kernels AND the timing events live on it
+    stream = torch.cuda.Stream(device=dev)
+    env.set_stream(stream.cuda_stream)
+
+    def run_steps(k, events=None):
+        left = k
+        while left > 0:
+            n = min(left, args.chunk)
+            if events is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+            env.run(args.policy, n, auto_reset=True)
+            if events is not None:
+                b.record(stream)
+                events.append((a, b, n))
+            left -= n
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run_steps(args.warmup)
+    events = []
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps, events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # statistics all-reduce (the path's only collective)
+    red, vec = env.reduce_counters()
+    stats = torch.from_numpy(vec.copy()).to(dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    stats = stats.cpu().numpy()
+
+    if rank == 0:
+        W = env.words_per_link
+        total_steps = B * world * args.steps
+        kernel_ms = [a.elapsed_time(b) for a, b, _ in events]
+        full = [(ms, n) for (ms, (_, _, n)) in zip(kernel_ms, events) if n == args.chunk] or list(zip(kernel_ms, [e[2] for e in events]))
+        avg_ms = float(np.mean([ms for ms, _ in full]))
+        n_per_launch = full[0][1]
+        A = algorithmic_bytes_per_env_step(topo, W)
+        achieved = A * B * n_per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env steps/sec (whole node) + blocking-prob parity, NSFNET RMSA 320 slots",
+            "value": total_steps / elapsed,
+            "unit": "env steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 bitmap + f64 statistics",
+            "data": "synthetic (reference's Poisson traffic generator run on the device, seeds 10+i)",
+            "config": {"workload": f"RMSA-v0 NSFNET 320 slots load 50, batch {B} envs per GPU, {args.policy} on device, "
+                                   f"stats={args.stats}, {args.chunk} env-steps per launch",
+                       "batch_per_gpu": B, "global_batch": B * world, "policy": args.policy, "stats_level": args.stats,
+                       "chunk": args.chunk, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "orlg_rmsa_kernel<5,%d>" % {"counters": 0, "network": 1, "full": 2}[args.stats],
+                         "kernel_ms_per_launch": avg_ms, "algorithmic_bytes_per_env_step": A,
+                         "env_steps_per_launch": B * n_per_launch},
+            "blocking": {"services_processed": int(stats[0]), "services_accepted": int(stats[1]),
+                         "service_blocking_rate": float((stats[0] - stats[1]) / max(1, stats[0])),
+                         "bit_rate_blocking_rate": float((stats[4] - stats[5]) / max(1, stats[4])),
+                         "episodes_done": int(stats[8]), "num_envs": int(stats[9])},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(topo)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
