@@ -1,7 +1,7 @@
 from . import _lib
 from ._lib import OrlgError
-from .batched import DEFAULT_BIT_RATES, BatchedRMSAEnv
+from .batched import DEFAULT_BIT_RATES, BatchedDeepRMSAEnv, BatchedRMSAEnv
 from .topology import FrozenTopology, Modulation, Path, Service, TopologyView, selection_tables
 
 __all__ = ["FrozenTopology", "Modulation", "Path", "Service", "TopologyView", "selection_tables",
-           "BatchedRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib"]
+           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib"]

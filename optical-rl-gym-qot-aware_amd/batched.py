@@ -241,3 +241,22 @@ class BatchedRMSAEnv:
         d = {n: int(a[i]) for i, n in enumerate(COUNTER_NAMES)}
         d["episodes_done"], d["num_envs"] = int(a[8]), int(a[9])
         return d, a
+
+
+class BatchedDeepRMSAEnv(BatchedRMSAEnv):
+    """B x DeepRMSAEnv (``deeprmsa_env.py:9-46``): load = holding / inter-arrival, reward +1/-1, actions in
+    Discrete(k*j + reject), observation = per-path free-block features."""
+
+    def __init__(self, topology, batch_size: int, *, j: int = 1, episode_length: int = 1000,
+                 mean_service_holding_time: float = 25.0, mean_service_inter_arrival_time: float = 0.1,
+                 num_spectrum_resources: int = 100, node_request_probabilities=None, seed=None, seeds=None,
+                 allow_rejection: bool = False, **extra):
+        super().__init__(topology, batch_size, episode_length=episode_length,
+                         load=mean_service_holding_time / mean_service_inter_arrival_time,
+                         mean_service_holding_time=mean_service_holding_time,
+                         num_spectrum_resources=num_spectrum_resources,
+                         node_request_probabilities=node_request_probabilities, seed=seed, seeds=seeds,
+                         allow_rejection=allow_rejection, j=j, reward_mode=1, **extra)
+
+    def step(self, actions, outputs=("reward", "done", "accepted")):
+        return self.step_deeprmsa(actions, outputs=outputs)

@@ -61,3 +61,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def nsfnet():
     return load_topology("nsfnet_chen_5-paths_6-modulations")
+
+
+def deeprmsa_to_rmsa_kwargs(kw):
+    """DeepRMSAEnv.__init__ (deeprmsa_env.py:10-32): load = holding / inter-arrival, S default 100."""
+    kw = dict(kw)
+    ht = kw.get("mean_service_holding_time", 25.0)
+    iat = kw.pop("mean_service_inter_arrival_time", 0.1)
+    j = kw.pop("j", 1)
+    out = dict(load=ht / iat, mean_service_holding_time=ht, num_spectrum_resources=kw.get("num_spectrum_resources", 100),
+               episode_length=kw.get("episode_length", 1000), seed=kw.get("seed"),
+               node_request_probabilities=kw.get("node_request_probabilities"))
+    return out, j

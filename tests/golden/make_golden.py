@@ -290,6 +290,80 @@ def gen_rmsa():
               "compactness", out["network_compactness"][-1])
 
 
+# --------------------------------------------------------------------------- DeepRMSA traces
+def run_deeprmsa_trace(topo, env_kwargs, policy, n_steps, reset_on_done, actions_seed):
+    from optical_rl_gym.envs import deeprmsa_env as D
+
+    env = D.DeepRMSAEnv(topology=topo, **env_kwargs)
+    pol = {"deeprmsa_sp_ff": D.shortest_path_first_fit, "deeprmsa_sap_ff": D.shortest_available_path_first_fit}.get(policy)
+    arng = np.random.default_rng(actions_seed)
+    rec = Recorder()
+    obs0 = env.observation()
+    obs = []
+    for _ in range(n_steps):
+        s = env.current_service
+        if pol is not None:
+            a = int(pol(env))
+        else:
+            a = int(arng.integers(0, env.k_paths * env.j + 1))  # k*j = rejection
+        o, reward, done, info = env.step(a)
+        obs.append(np.asarray(o, dtype=np.float64))
+        av = env.topology.graph["available_slots"]
+        rec.add(
+            service_id=s.service_id, src_id=s.source_id, dst_id=s.destination_id, bit_rate=s.bit_rate,
+            arrival=s.arrival_time, holding=s.holding_time, action=a, accepted=bool(s.accepted),
+            act_slot=int(s.initial_slot) if s.accepted else env.num_spectrum_resources,
+            reward=float(reward), done=bool(done),
+            services_processed=env.services_processed, services_accepted=env.services_accepted,
+            episode_services_processed=env.episode_services_processed,
+            episode_services_accepted=env.episode_services_accepted,
+            bit_rate_requested=env.bit_rate_requested, bit_rate_provisioned=env.bit_rate_provisioned,
+            network_compactness=float(info["network_compactness"]),
+            free_total=int(av.sum()), occ_crc=occ_crc(av), current_time=env.current_time,
+        )
+        if done and reset_on_done:
+            env.reset()
+    out = rec.arrays()
+    out["action"] = out["action"].astype(np.int32)
+    out["obs0"] = np.asarray(obs0, dtype=np.float64)
+    out["obs"] = np.stack(obs)
+    out["final_available_slots"] = np.packbits(
+        env.topology.graph["available_slots"].astype(np.uint8), axis=1, bitorder="little")
+    return out
+
+
+DEEPRMSA_BASE = dict(seed=10, allow_rejection=False, mean_service_holding_time=7.5,
+                     mean_service_inter_arrival_time=1.0 / 12.0, j=1, episode_length=50,
+                     node_request_probabilities=np.array(DEEPRMSA_NODE_PROBS))
+
+DEEPRMSA_CASES = [
+    # tests/test_deeprmsa.py:30-47 configuration (S = the class default 100) and the BASELINE S=320 variant
+    ("deeprmsa_nsfnet_s10_sapff", "nsfnet_chen_5-paths_6-modulations", dict(), "deeprmsa_sap_ff", 1000, True),
+    ("deeprmsa_nsfnet_s10_spff", "nsfnet_chen_5-paths_6-modulations", dict(), "deeprmsa_sp_ff", 600, True),
+    ("deeprmsa_nsfnet_s10_sapff_320", "nsfnet_chen_5-paths_6-modulations",
+     dict(num_spectrum_resources=320, node_request_probabilities=None, mean_service_inter_arrival_time=1.0 / 24.0),
+     "deeprmsa_sap_ff", 1000, True),
+    ("deeprmsa_nsfnet_s4_random_j3", "nsfnet_chen_5-paths_6-modulations",
+     dict(seed=4, j=3, num_spectrum_resources=160, mean_service_inter_arrival_time=1.0 / 10.0), "random", 1000, True),
+    ("deeprmsa_jpn12_s6_random_j2", "jpn12_3-paths_6-modulations",
+     dict(seed=6, j=2, num_spectrum_resources=100, node_request_probabilities=None,
+          mean_service_inter_arrival_time=1.0 / 20.0, episode_length=200), "random", 800, True),
+]
+
+
+def gen_deeprmsa():
+    for name, tname, over, policy, steps, reset in DEEPRMSA_CASES:
+        kw = dict(DEEPRMSA_BASE)
+        kw.update(over)
+        topo = load_pickled_topology(TOPOLOGIES[tname])
+        out = run_deeprmsa_trace(topo, kw, policy, steps, reset, kw.get("seed", 0) + 2000)
+        meta = dict(topology=tname, env_kwargs=_jsonable(kw), policy=policy, steps=steps, reset_on_done=reset)
+        out["meta"] = np.array(json.dumps(meta))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "accepted", int(out["services_accepted"][-1]), "/", int(out["services_processed"][-1]),
+              "obs dim", out["obs"].shape[1])
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
