@@ -39,6 +39,7 @@ struct orlg_env {
     hipStream_t stream;
     bool own_stream;
     size_t lds_block_bytes;
+    int waves_per_block;
     int num_paths;
     // owned device buffers
     std::vector<void *> bufs;
@@ -118,7 +119,7 @@ __global__ void orlg_extract_kernel(OrlgParams p, int what, unsigned char *out) 
         for (size_t i = tid; i < B; i += nth) {
             const OrlgEnvScalars &s = p.scal[i];
             o[i].service_id = s.req_sid; o[i].src = s.req_src; o[i].dst = s.req_dst;
-            o[i].bit_rate = p.bit_rates[s.req_br];
+            o[i].bit_rate = reinterpret_cast<const int32_t *>(p.tables + p.t_bitrates)[s.req_br];
             o[i].arrival_time = s.req_arrival; o[i].holding_time = s.req_holding;
         }
     } else if (what == EX_COUNTERS) {
@@ -214,7 +215,8 @@ static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
-    dim3 grid((p.B + ORLG_WAVES_PER_BLOCK - 1) / ORLG_WAVES_PER_BLOCK), block(ORLG_WAVE * ORLG_WAVES_PER_BLOCK);
+    const int wpb = e->waves_per_block;
+    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, p);
     HIP_TRY(hipGetLastError());
     return ORLG_OK;
@@ -346,17 +348,21 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     p.l_hist = off; off = up16(off + 4 * NBR * 4);
     p.l_lint = off; off = up16(off + E * 4);
     p.l_scratch = off; off = up16(off + 64 * 16);
+    p.l_wsc = off; off = up16(off + (int)sizeof(OrlgWaveScalars));
     p.l_wave_bytes = off;
-    e->lds_block_bytes = (size_t)off * ORLG_WAVES_PER_BLOCK;
-    if (e->lds_block_bytes > 160 * 1024) {
-        orlg_destroy(e);
-        return fail(ORLG_ERR_INVALID, "environment state (%zu B per workgroup) exceeds the 160 KiB LDS", e->lds_block_bytes);
-    }
 
     int rc = ORLG_OK;
 #define TRY(x) do { rc = (x); if (rc) { orlg_destroy(e); return rc; } } while (0)
-    // read-only tables
+    // read-only tables: one blob, staged into LDS by every workgroup (layout = OrlgParams::t_*)
     {
+        std::vector<unsigned char> blob;
+        auto put = [&](const void *src, size_t bytes) {
+            size_t at = blob.size();
+            blob.resize((at + bytes + 15) & ~(size_t)15, 0);
+            memcpy(blob.data() + at, src, bytes);
+            return (int32_t)at;
+        };
+        p.t_pair = put(t->pair_path_base, (size_t)N * N * 4);
         std::vector<OrlgPathRec> recs(t->num_paths);
         for (int g = 0; g < t->num_paths; g++) {
             memset(&recs[g], 0, sizeof(OrlgPathRec));
@@ -373,7 +379,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
                 recs[g].link[i] = (uint8_t)l;
             }
         }
-        OrlgPathRec *d_recs; TRY(dev_upload(e, &d_recs, recs.data(), recs.size())); p.recs = d_recs;
+        p.t_recs = put(recs.data(), recs.size() * sizeof(OrlgPathRec));
         // get_number_slots (rmsa_env.py:708-719): ceil(bit_rate / (SE * channel_width)) + 1
         std::vector<uint16_t> ns((size_t)NBR * ORLG_NSLOT_STRIDE, 0);
         for (int b = 0; b < NBR; b++)
@@ -382,13 +388,35 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
                 double n = std::ceil(q) + 1;
                 ns[(size_t)b * ORLG_NSLOT_STRIDE + se] = (uint16_t)(n > 65535 ? 65535 : n);
             }
-        uint16_t *d_ns; TRY(dev_upload(e, &d_ns, ns.data(), ns.size())); p.nslots_tab = d_ns;
-        int32_t *d_i; double *d_d;
-        TRY(dev_upload(e, &d_i, t->pair_path_base, (size_t)N * N)); p.pair_base = d_i;
-        TRY(dev_upload(e, &d_i, c->bit_rates, (size_t)NBR)); p.bit_rates = d_i;
-        TRY(dev_upload(e, &d_d, c->bit_rate_cum, (size_t)NBR)); p.br_cum = d_d;
-        TRY(dev_upload(e, &d_d, c->src_cum, (size_t)N)); p.src_cum = d_d;
-        TRY(dev_upload(e, &d_d, c->dst_cum, (size_t)N * N)); p.dst_cum = d_d;
+        p.t_nslots = put(ns.data(), ns.size() * 2);
+        p.t_bitrates = put(c->bit_rates, (size_t)NBR * 4);
+        p.t_brcum = put(c->bit_rate_cum, (size_t)NBR * 8);
+        p.t_srccum = put(c->src_cum, (size_t)N * 8);
+        p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
+        // exact quotient tables for _update_link_stats: k / S (rmsa_env.py:567-574) and 1 / u (:620-622)
+        std::vector<double> util(S + 1), inv(S + 2);
+        for (int k = 0; k <= S; k++) util[k] = (double)k / (double)S;
+        inv[0] = 0.0;
+        for (int u = 1; u < S + 2; u++) inv[u] = 1.0 / (double)u;
+        p.t_util = put(util.data(), util.size() * 8);
+        p.t_inv = put(inv.data(), inv.size() * 8);
+        p.tab_bytes = (int32_t)blob.size();
+        p.l_outs = p.tab_bytes;
+        p.l_shared_bytes = p.tab_bytes + up16(ORLG_NUM_OUTS * 8);
+        unsigned char *d_blob; TRY(dev_upload(e, &d_blob, blob.data(), blob.size())); p.tables = d_blob;
+    }
+    // environments (waves) per workgroup: as many as fit in the 160 KiB of LDS next to the staged tables, so
+    // that two workgroups still fit on a CU when possible
+    {
+        int wpb = ORLG_MAX_WAVES_PER_BLOCK;
+        while (wpb > 1 && (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 80 * 1024) wpb >>= 1;
+        if ((size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 160 * 1024) {
+            size_t need = (size_t)p.l_shared_bytes + (size_t)p.l_wave_bytes;
+            orlg_destroy(e);
+            return fail(ORLG_ERR_INVALID, "tables + one environment (%zu B) exceed the 160 KiB LDS", need);
+        }
+        e->waves_per_block = wpb;
+        e->lds_block_bytes = (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes;
     }
     // per-env state
     TRY(dev_alloc(e, &p.occ, (size_t)batch * p.NW));
@@ -482,21 +510,21 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
         }
     }
     // outputs: write straight into device pointers, stage host pointers
-    struct Slot { void *user; size_t elem; void **kptr; };
+    struct Slot { void *user; size_t elem; };
     const size_t cnt = (size_t)n_steps * p.B;
-    Slot slots[10] = {
-        {io ? io->act_path : nullptr, 4, (void **)&p.o_path},       {io ? io->act_slot : nullptr, 4, (void **)&p.o_slot},
-        {io ? io->accepted : nullptr, 1, (void **)&p.o_accepted},   {io ? io->done : nullptr, 1, (void **)&p.o_done},
-        {io ? io->reward : nullptr, 8, (void **)&p.o_reward},       {io ? io->request : nullptr, 16, (void **)&p.o_request},
-        {io ? io->arrival : nullptr, 8, (void **)&p.o_arrival},     {io ? io->holding : nullptr, 8, (void **)&p.o_holding},
-        {io ? io->network_compactness : nullptr, 8, (void **)&p.o_compact},
-        {io ? io->network_compactness_difference : nullptr, 8, (void **)&p.o_compact_diff}};
-    bool staged[10] = {false};
-    for (int i = 0; i < 10; i++) {
-        *slots[i].kptr = nullptr;
+    Slot slots[ORLG_NUM_OUTS] = {
+        {io ? io->act_path : nullptr, 4},   {io ? io->act_slot : nullptr, 4},  {io ? io->accepted : nullptr, 1},
+        {io ? io->done : nullptr, 1},       {io ? io->reward : nullptr, 8},    {io ? io->request : nullptr, 16},
+        {io ? io->arrival : nullptr, 8},    {io ? io->holding : nullptr, 8},   {io ? io->network_compactness : nullptr, 8},
+        {io ? io->network_compactness_difference : nullptr, 8}};
+    bool staged[ORLG_NUM_OUTS] = {false};
+    p.out_mask = 0;
+    for (int i = 0; i < ORLG_NUM_OUTS; i++) {
+        p.outs[i] = nullptr;
         if (!slots[i].user) continue;
+        p.out_mask |= 1 << i;
         if (is_device_ptr(slots[i].user)) {
-            *slots[i].kptr = slots[i].user;
+            p.outs[i] = slots[i].user;
         } else {
             size_t bytes = cnt * slots[i].elem;
             if (bytes > e->io_cap[i]) {
@@ -505,14 +533,14 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
                 HIP_TRY(hipMalloc(&e->io_buf[i], bytes));
                 e->io_cap[i] = bytes;
             }
-            *slots[i].kptr = e->io_buf[i];
+            p.outs[i] = e->io_buf[i];
             staged[i] = true;
         }
     }
     int rc = launch_rmsa(e, p);
     if (rc) return rc;
     bool any = false;
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < ORLG_NUM_OUTS; i++)
         if (staged[i]) {
             HIP_TRY(hipMemcpyAsync(slots[i].user, e->io_buf[i], cnt * slots[i].elem, hipMemcpyDeviceToHost, e->stream));
             any = true;
@@ -609,7 +637,7 @@ int orlg_query_path_masks(orlg_env *e, int32_t env_index, uint64_t *masks, int32
     masks_kernel_t k = pick_masks(e->W);
     u64 *dm = reinterpret_cast<u64 *>(e->staging);
     int32_t *dn = reinterpret_cast<int32_t *>(e->staging + ((mbytes + 15) & ~(size_t)15));
-    hipLaunchKernelGGL(k, dim3(1), dim3(ORLG_WAVE), (size_t)e->p.NW * 8, e->stream, e->p, env_index, dm, dn);
+    hipLaunchKernelGGL(k, dim3(1), dim3(ORLG_WAVE), (size_t)e->p.l_shared_bytes + (size_t)e->p.NW * 8, e->stream, e->p, env_index, dm, dn);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(masks, dm, mbytes, hipMemcpyDefault, e->stream));
     HIP_TRY(hipMemcpyAsync(nslots, dn, nbytes, hipMemcpyDefault, e->stream));
@@ -632,8 +660,10 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
         p.o_obs = out;
     }
     rmsa_kernel_t k = pick_obs(e->W);
-    size_t lds = (size_t)(((p.NW * 8 + 15) & ~15)) * ORLG_WAVES_PER_BLOCK;
-    dim3 grid((p.B + ORLG_WAVES_PER_BLOCK - 1) / ORLG_WAVES_PER_BLOCK), block(ORLG_WAVE * ORLG_WAVES_PER_BLOCK);
+    const int wpb = e->waves_per_block;
+    size_t lds = (size_t)p.l_shared_bytes + (size_t)(((p.NW * 8 + 15) & ~15)) * wpb;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds, e->stream, p);
     HIP_TRY(hipGetLastError());
     if (!dev) return copy_out(e, out, e->staging, bytes);

@@ -4,12 +4,13 @@
 #include <stdint.h>
 
 #define ORLG_WAVE 64
-#define ORLG_WAVES_PER_BLOCK 4
+#define ORLG_MAX_WAVES_PER_BLOCK 8
 #define ORLG_MT_N 624
 #define ORLG_MT_M 397
 #define ORLG_MAX_W 8          // 64-bit words per link: S <= 512
 #define ORLG_MAX_HOPS 14
 #define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
+#define ORLG_NUM_OUTS 10
 
 // One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
 // "index" of every hop (utils.py:27-36, rmsa_env.py:479-483).
@@ -18,7 +19,7 @@ struct __attribute__((aligned(16))) OrlgPathRec {
     uint8_t link[ORLG_MAX_HOPS];
 };
 
-// Per-environment scalars kept in HBM between launches (one record per env, 256 B).
+// Per-environment scalars kept in HBM between launches (one record per env, 192 B).
 struct __attribute__((aligned(16))) OrlgEnvScalars {
     double current_time;                                   // optical_network_env.py:33
     double req_arrival, req_holding;                       // current_service.arrival_time / holding_time
@@ -36,17 +37,31 @@ struct __attribute__((aligned(16))) OrlgEnvScalars {
 };
 static_assert(sizeof(OrlgEnvScalars) == 192, "OrlgEnvScalars layout");
 
+// Wave scalars that live in LDS during a launch (rarely touched counters; lane 0 updates them).
+struct OrlgWaveScalars {
+    int64_t c[8];
+    int64_t sum_bitrate_running;
+    int64_t episodes_done;
+    double g_thr, g_comp, g_lu;        // topology.graph["throughput" | "compactness" | "last_update"]
+    double req_arrival, req_holding;   // pending request times
+    int32_t n_running, q_overflow;
+};
+static_assert(sizeof(OrlgWaveScalars) == 128, "OrlgWaveScalars layout");
+
 enum { ORLG_MODE_STEP = 0, ORLG_MODE_INIT = 1, ORLG_MODE_EPISODE_RESET = 2 };
 // device-side policy ids (== include/orlg.h ORLG_POLICY_*)
 enum { ORLG_POLICY_EXT = -1, ORLG_POLICY_SP = 0, ORLG_POLICY_SAP = 1, ORLG_POLICY_LLP = 2, ORLG_POLICY_DEEP_SP = 3,
        ORLG_POLICY_DEEP_SAP = 4, ORLG_POLICY_DEEP_EXT = 5 };
+// per-step output slots (OrlgParams::outs)
+enum { ORLG_OUT_PATH = 0, ORLG_OUT_SLOT, ORLG_OUT_ACCEPTED, ORLG_OUT_DONE, ORLG_OUT_REWARD, ORLG_OUT_REQUEST,
+       ORLG_OUT_ARRIVAL, ORLG_OUT_HOLDING, ORLG_OUT_COMPACT, ORLG_OUT_COMPACT_DIFF };
 
 // Kernel parameters (passed by value).
 struct OrlgParams {
     // sizes
     int32_t B, N, E, S, K, NBR, Q, NW;       // NW = E*W words of occupancy per env
     int32_t episode_length, n_steps, policy, auto_reset, mode, reward_mode, stats_level, j;
-    int32_t obs_dim, pad0;
+    int32_t obs_dim, out_mask;               // out_mask: bit i set <=> outs[i] != nullptr
     double arrival_lambda, holding_lambda;
     // per-env state in HBM
     uint64_t *occ;            // [B][NW]   free-slot bitmap, word (link*W + w)
@@ -56,18 +71,24 @@ struct OrlgParams {
     OrlgEnvScalars *scal;     // [B]
     int32_t *hist;            // [B][4][NBR] requested, provisioned, episode requested, episode provisioned
     double *lstat;            // [B][4][E] utilization, external_fragmentation, compactness, last_update
-    // read-only tables (shared by all envs)
-    const int32_t *pair_base;       // [N*N]
-    const OrlgPathRec *recs;        // [num_paths]
-    const uint16_t *nslots_tab;     // [NBR][8]
-    const int32_t *bit_rates;       // [NBR]
-    const double *br_cum, *src_cum, *dst_cum;
+    // read-only tables: ONE blob in HBM that every workgroup stages into LDS (byte offsets t_*, 16-B aligned)
+    const unsigned char *tables;
+    int32_t tab_bytes;
+    int32_t t_pair;           // int32  [N*N]        first path record of pair (src, dst)
+    int32_t t_recs;           // PathRec[num_paths]
+    int32_t t_nslots;         // uint16 [NBR][8]     get_number_slots per (bit rate, spectral efficiency)
+    int32_t t_bitrates;       // int32  [NBR]
+    int32_t t_brcum;          // double [NBR]
+    int32_t t_srccum;         // double [N]
+    int32_t t_dstcum;         // double [N*N]
+    int32_t t_util;           // double [S+1]        k / S
+    int32_t t_inv;            // double [S+2]        1 / u
     // per-call IO
     const int32_t *actions;
-    int32_t *o_path, *o_slot, *o_request;
-    uint8_t *o_accepted, *o_done;
-    double *o_reward, *o_arrival, *o_holding, *o_compact, *o_compact_diff;
+    void *outs[ORLG_NUM_OUTS];
     double *o_obs;
     // per-wave LDS layout (byte offsets from the wave's base) and size
-    int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wave_bytes, pad1;
+    int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_wave_bytes;
+    int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions
+    int32_t l_outs;           // byte offset of the staged outs[] array
 };

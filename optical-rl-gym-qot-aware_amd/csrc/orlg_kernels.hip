@@ -1,14 +1,16 @@
 // orlg_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the batched RMSA / DeepRMSA step() path.
 //
-// Execution model: ONE WAVEFRONT PER ENVIRONMENT.  A 256-thread workgroup carries four environments;
-// nothing is shared between the waves of a workgroup, so there is no __syncthreads() anywhere and a
-// wave whose environment index is out of range simply exits.  For the duration of a launch (n_steps
-// steps) the wave keeps its environment on chip:
+// Execution model: ONE WAVEFRONT PER ENVIRONMENT.  A workgroup carries up to eight environments (one
+// per wave).  The only thing its waves share is a read-only copy of the topology tables staged into
+// LDS at kernel start (path records = per-path link index sets, pair table, number-of-slots table,
+// cumulative weight tables): one __syncthreads() after staging, none afterwards.  For the duration of a
+// launch (n_steps steps) each wave keeps its environment on chip:
 //     LDS (per wave)   link x slot free bitmap  E*W uint64        (occ)
 //                      release queue            Q x (f64 time, u32 descriptor)
 //                      MT19937 state            624 x u32
-//                      per-link statistics      4 x E f64, per-link (span, gaps) cache, histograms
-//     SGPR/VGPR        wave-uniform scalars: clock, pending request, counters, running sums
+//                      per-link statistics      4 x E f64, per-link (span, gaps) cache, histograms,
+//                      rarely touched counters  (OrlgWaveScalars)
+//     SGPR/VGPR        wave-uniform scalars: clock, pending request, integer sums for the compactness
 // and reads / writes the HBM copy exactly once, with lane-contiguous (coalesced) accesses.
 // Within a step the 64 lanes are used as
 //     (path, word) lanes  to AND the link bitmaps of the k candidate paths   (get_available_slots)
@@ -17,7 +19,8 @@
 //     (hop, word) lanes   to provision / release a slot window and to rebuild the link statistics
 //     queue lanes         to find expired services with one ballot per 64 queue slots
 //     node / rate lanes   for CPython's bisect in random.choices
-// All fp64 arithmetic repeats the reference's operations one for one (compile with -ffp-contract=off).
+// All fp64 arithmetic reproduces the reference's IEEE operations one for one (compile with
+// -ffp-contract=off; the explicit fma() calls below are the hardware's own division sequence).
 //
 // Reference: optical_rl_gym/envs/rmsa_env.py (step :222-341, _provision_path :462-513, _release_path
 // :515-535, _update_network_stats :537-560, _update_link_stats :562-641, _next_service :643-695,
@@ -71,8 +74,36 @@ DEV u64 window_mask(int s, int n, int w) {
     return m << lo;
 }
 
-// ---------------------------------------------------------------------------------------- wave context
-struct Wave {
+// ---------------------------------------------------------------------------------------- fp64 division
+// x / b for several numerators over ONE denominator.  This is the gfx9 fdiv-f64 expansion itself
+// (v_rcp_f64, two Newton steps, quotient, residual, final fma) with the denominator-only part hoisted;
+// v_div_scale / v_div_fixup are identities for the operand ranges here (simulation clock in
+// (0, 1e12), numerators below 1e18), so every quotient is the correctly rounded IEEE quotient the
+// reference computes.  Checked bit for bit against the oracle in tests/test_gpu_rmsa.py.
+DEV double recip_refine(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+DEV double div_by(double a, double b, double y) {
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+
+// ---------------------------------------------------------------------------------------- contexts
+struct Tab {  // topology tables staged in LDS (shared by the waves of a workgroup, read-only)
+    const int32_t *pair_base;
+    const OrlgPathRec *recs;
+    const uint16_t *nslots;
+    const int32_t *bit_rates;
+    const double *br_cum, *src_cum, *dst_cum, *util_tab, *inv_tab;
+    const u64 *outs;
+};
+
+struct Wave {  // this wave's environment in LDS
     int lane;
     u64 *occ;
     double *qtime;
@@ -82,7 +113,35 @@ struct Wave {
     int32_t *hist; // [4][NBR]
     int32_t *lint; // [E] span | gaps << 16
     uint32_t *scratch;
+    OrlgWaveScalars *wsc;
 };
+
+DEV Tab make_tab(unsigned char *smem, const OrlgParams &p) {
+    Tab tb;
+    tb.pair_base = reinterpret_cast<const int32_t *>(smem + p.t_pair);
+    tb.recs = reinterpret_cast<const OrlgPathRec *>(smem + p.t_recs);
+    tb.nslots = reinterpret_cast<const uint16_t *>(smem + p.t_nslots);
+    tb.bit_rates = reinterpret_cast<const int32_t *>(smem + p.t_bitrates);
+    tb.br_cum = reinterpret_cast<const double *>(smem + p.t_brcum);
+    tb.src_cum = reinterpret_cast<const double *>(smem + p.t_srccum);
+    tb.dst_cum = reinterpret_cast<const double *>(smem + p.t_dstcum);
+    tb.util_tab = reinterpret_cast<const double *>(smem + p.t_util);
+    tb.inv_tab = reinterpret_cast<const double *>(smem + p.t_inv);
+    tb.outs = reinterpret_cast<const u64 *>(smem + p.l_outs);
+    return tb;
+}
+
+// stage the table blob (and the per-call output pointers) into LDS; every thread of the workgroup takes part
+DEV void stage_tables(unsigned char *smem, const OrlgParams &p) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(p.tables);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    const int n16 = p.tab_bytes >> 4;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < ORLG_NUM_OUTS; ++i)
+        if ((int)threadIdx.x == i) reinterpret_cast<u64 *>(smem + p.l_outs)[i] = reinterpret_cast<u64>(p.outs[i]);
+    __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------------- MT19937
 // Regenerate all 624 words in place (CPython _randommodule.c genrand_uint32).  Sub-round r handles
@@ -208,33 +267,52 @@ DEV int rec_byte(u64 lo, u64 hi, int i) { return (int)(((i < 8 ? lo >> (8 * i) :
 
 // AND of the link bitmaps of path record `gid` for word w (get_available_slots, rmsa_env.py:745-756)
 template <int W>
-DEV u64 path_word(const Wave &wv, const OrlgPathRec *recs, int gid, int w) {
+DEV u64 path_word(const u64 *occ, const OrlgPathRec *recs, int gid, int w) {
     const u64 *rp = reinterpret_cast<const u64 *>(recs + gid);
     u64 lo = rp[0], hi = rp[1];
     int hops = (int)(lo & 0xff);
     u64 acc = ~0ull;
-    for (int h = 0; h < hops; ++h) acc &= wv.occ[rec_byte(lo, hi, 2 + h) * W + w];
+    for (int h = 0; h < hops; ++h) acc &= occ[rec_byte(lo, hi, 2 + h) * W + w];
     return acc;
 }
 
+// _get_network_compactness (rmsa_env.py:844-851) from the maintained integer sums
+DEV double network_compactness(int sum_span, int sum_slots_hops, int sum_gaps, int E) {
+    if (sum_gaps > 0) return ((double)sum_span / (double)sum_slots_hops) * ((double)E / (double)sum_gaps);
+    return 1.0;
+}
+
+// kernel parameters re-read from the kernarg segment through an opaque pointer: lets the compiler drop
+// rarely used pointers from SGPRs across the step loop instead of spilling them
+typedef const OrlgParams __attribute__((address_space(4))) *KernargParams;
+DEV KernargParams kernarg_params() {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return (KernargParams)k;
+}
+
 // ---------------------------------------------------------------------------------------- link statistics
-// Rebuild, for a list of links, the integer run statistics of the link's free bitmap and (FULL) the
-// time-weighted floats of _update_link_stats (rmsa_env.py:562-641).  Also maintains the per-link
-// (span, gaps) cache whose sums give _get_network_compactness (rmsa_env.py:806-851):
+// Rebuild, for a list of links, the integer run statistics of the link's free bitmap and (LINKF) the
+// time-weighted floats of _update_link_stats (rmsa_env.py:562-641).  Maintains the per-link (span, gaps)
+// cache whose sums give _get_network_compactness (rmsa_env.py:806-851):
 //     span = lambda_max - lambda_min, gaps = free runs inside the used span = used runs - 1
-// for links with more than one used run, 0 otherwise.  links == nullptr means links h0..h0+n-1.
-template <int W, bool FLOATS>
-DEV void link_stats_update(Wave &wv, const OrlgParams &p, const uint8_t *links, int first, int nlinks, double now,
-                           int &sum_span, int &sum_gaps) {
+// for links with more than one used run, 0 otherwise.  links == nullptr means links 0..nlinks-1.
+// GRAPH: after the last chunk also perform _update_network_stats (rmsa_env.py:537-560) -- its two
+// time-weighted averages ride on lanes 62 / 63 of the same fp64 instruction stream as the links'.
+template <int W, bool LINKF, bool GRAPH>
+DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
+                           int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr) {
     constexpr int HPC = 64 / W;  // links per chunk
     const int lane = wv.lane;
-    const int S = p.S, E = p.E;
     const int hl = lane / W, w = lane - hl * W;
+    double ynow = 0.0;
+    if ((LINKF || GRAPH) && now > 0) ynow = recip_refine(now);
     for (int h0 = 0; h0 < nlinks; h0 += HPC) {
-        int nl = nlinks - h0 < HPC ? nlinks - h0 : HPC;
+        const int nl = nlinks - h0 < HPC ? nlinks - h0 : HPC;
+        const bool last_chunk = h0 + HPC >= nlinks;
         // ---- phase A: (link, word) lanes
         if (hl < nl) {
-            int link = links ? (int)links[first + h0 + hl] : first + h0 + hl;
+            int link = links ? (int)links[h0 + hl] : h0 + hl;
             const u64 *row = wv.occ + link * W;
             u64 x = row[w];
             u64 prev = w > 0 ? row[w - 1] : 0ull;
@@ -247,7 +325,7 @@ DEV void link_stats_update(Wave &wv, const OrlgParams &p, const uint8_t *links, 
             int lo = u ? 64 * w + ctz64(u) : 0x7fff;
             int hi = u ? 64 * w + 64 - clz64(u) : 0;
             int ml = 0;
-            if (FLOATS) {
+            if (LINKF) {
                 int e = 0;
                 if ((x >> 63) && w < W - 1) {
                     for (int w2 = w + 1; w2 < W; ++w2) {
@@ -270,11 +348,11 @@ DEV void link_stats_update(Wave &wv, const OrlgParams &p, const uint8_t *links, 
             sc[2] = (uint32_t)lo | ((uint32_t)hi << 16);
         }
         wave_sync();
-        // ---- phase B: one lane per link
+        // ---- phase B (integers): one lane per link
         int dspan = 0, dgaps = 0;
+        int link = 0, freec = 0, F = 0, U = 0, ml = 0, lmin = 0x7fff, lmax = 0;
         if (lane < nl) {
-            int link = links ? (int)links[first + h0 + lane] : first + h0 + lane;
-            int freec = 0, F = 0, U = 0, ml = 0, lmin = 0x7fff, lmax = 0;
+            link = links ? (int)links[h0 + lane] : h0 + lane;
 #pragma unroll
             for (int q = 0; q < W; ++q) {
                 const uint32_t *sc = wv.scratch + (lane * W + q) * 4;
@@ -293,53 +371,68 @@ DEV void link_stats_update(Wave &wv, const OrlgParams &p, const uint8_t *links, 
             wv.lint[link] = nspan | (ngaps << 16);
             dspan = nspan - (old & 0xffff);
             dgaps = ngaps - (old >> 16);
-            if (FLOATS) {
-                double *l_util = wv.lst, *l_ef = wv.lst + E, *l_c = wv.lst + 2 * E, *l_lu = wv.lst + 3 * E;
-                double last_update = l_lu[link];
-                double time_diff = now - last_update;
-                if (now > 0) {
-                    const u64 *row = wv.occ + link * W;
-                    bool first_free = row[0] & 1ull;
-                    bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
-                    double cur_util = (double)(S - freec) / (double)S;
-                    l_util[link] = ((l_util[link] * last_update) + (cur_util * time_diff)) / now;
-                    double cur_ef = 0.0, cur_c = 0.0;
-                    if (freec > 0) {
-                        int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
-                        cur_ef = 1.0 - ((double)max_empty / (double)freec);
-                        cur_c = U > 1 ? ((double)(lmax - lmin) / (double)(S - freec)) * (1.0 / (double)U) : 1.0;
-                    }
-                    l_ef[link] = ((l_ef[link] * last_update) + (cur_ef * time_diff)) / now;
-                    l_c[link] = ((l_c[link] * last_update) + (cur_c * time_diff)) / now;
-                }
-                l_lu[link] = now;
-            }
         }
         for (int q = 0; q < nl; ++q) {
             sum_span += __builtin_amdgcn_readlane(dspan, q);
             sum_gaps += __builtin_amdgcn_readlane(dgaps, q);
         }
+        const bool graph_now = GRAPH && last_chunk;
+        if (graph_now) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
+        // ---- phase B (floats): links on lanes < nl, graph throughput / compactness on lanes 62 / 63
+        if ((LINKF || graph_now) && now > 0) {
+            const bool is_link = LINKF && lane < nl;
+            const bool is_graph = graph_now && lane >= 62;
+            if (is_link || is_graph) {
+                double *l_util = wv.lst, *l_ef = wv.lst + E, *l_c = wv.lst + 2 * E, *l_lu = wv.lst + 3 * E;
+                double last_update, last0, cur0;
+                double last1 = 0.0, last2 = 0.0, cur1 = 0.0, cur2 = 0.0;
+                if (is_link) {
+                    last_update = l_lu[link];
+                    last0 = l_util[link]; last1 = l_ef[link]; last2 = l_c[link];
+                    const u64 *row = wv.occ + link * W;
+                    bool first_free = row[0] & 1ull;
+                    bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
+                    cur0 = tb.util_tab[S - freec];  // (S - free) / S
+                    if (freec > 0) {
+                        int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
+                        cur1 = 1.0 - ((double)max_empty / (double)freec);
+                        cur2 = U > 1 ? ((double)(lmax - lmin) / (double)(S - freec)) * tb.inv_tab[U] : 1.0;
+                    }
+                } else {
+                    last_update = wv.wsc->g_lu;
+                    last0 = lane == 62 ? wv.wsc->g_thr : wv.wsc->g_comp;
+                    cur0 = lane == 62 ? cur_thr : comp_cur;
+                }
+                double time_diff = now - last_update;
+                double n0 = div_by((last0 * last_update) + (cur0 * time_diff), now, ynow);
+                if (is_link) {
+                    double n1 = div_by((last1 * last_update) + (cur1 * time_diff), now, ynow);
+                    double n2 = div_by((last2 * last_update) + (cur2 * time_diff), now, ynow);
+                    l_util[link] = n0; l_ef[link] = n1; l_c[link] = n2;
+                } else if (lane == 62) {
+                    wv.wsc->g_thr = n0;
+                } else {
+                    wv.wsc->g_comp = n0;
+                }
+            }
+        }
+        if (LINKF && lane < nl) wv.lst[3 * E + link] = now;
+        wave_sync();
+        if (graph_now && lane == 0) wv.wsc->g_lu = now;
         wave_sync();
     }
 }
 
-// _get_network_compactness (rmsa_env.py:844-851) from the maintained integer sums
-DEV double network_compactness(int sum_span, int sum_slots_hops, int sum_gaps, int E) {
-    if (sum_gaps > 0) return ((double)sum_span / (double)sum_slots_hops) * ((double)E / (double)sum_gaps);
-    return 1.0;
-}
-
-// set (release) or clear (provision) the window [s, s+n) on every link of path record gid
+// set (release) or clear (provision) the window [s, s+n) on every link of a path
 template <int W>
-DEV void apply_window(Wave &wv, const OrlgPathRec *recs, int gid, int hops, int s, int n, bool set_free) {
+DEV void apply_window(Wave &wv, const uint8_t *links, int hops, int s, int n, bool set_free) {
     constexpr int HPC = 64 / W;
-    const uint8_t *rb = reinterpret_cast<const uint8_t *>(recs + gid);
     const int hl = wv.lane / W, w = wv.lane - hl * W;
     u64 m = window_mask(s, n, w);
     for (int h0 = 0; h0 < hops; h0 += HPC) {
         int h = h0 + hl;
         if (hl < HPC && h < hops && m) {
-            u64 *word = wv.occ + (int)rb[2 + h] * W + w;
+            u64 *word = wv.occ + (int)links[h] * W + w;
             *word = set_free ? (*word | m) : (*word & ~m);
         }
     }
@@ -348,13 +441,15 @@ DEV void apply_window(Wave &wv, const OrlgPathRec *recs, int gid, int hops, int 
 
 // ---------------------------------------------------------------------------------------- the step kernel
 template <int W, int STATS>
-__global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_kernel(const OrlgParams p) {
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
+    stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
-    const int env = blockIdx.x * ORLG_WAVES_PER_BLOCK + wib;
+    const int env = blockIdx.x * (int)(blockDim.x >> 6) + wib;
     if (env >= p.B) return;
-    unsigned char *wb = smem + (size_t)wib * p.l_wave_bytes;
+    const Tab tb = make_tab(smem, p);
+    unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * p.l_wave_bytes;
     Wave wv;
     wv.lane = lane;
     wv.occ = reinterpret_cast<u64 *>(wb + p.l_occ);
@@ -365,6 +460,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
     wv.hist = reinterpret_cast<int32_t *>(wb + p.l_hist);
     wv.lint = reinterpret_cast<int32_t *>(wb + p.l_lint);
     wv.scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);
+    wv.wsc = reinterpret_cast<OrlgWaveScalars *>(wb + p.l_wsc);
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     constexpr bool NET = STATS >= 1;
@@ -387,44 +483,52 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
         for (int i = lane; i < 4 * NBR; i += 64) wv.hist[i] = gh[i];
         for (int i = lane; i < E; i += 64) wv.lint[i] = 0;
     }
-    OrlgEnvScalars sc = p.scal[env];
+    const OrlgEnvScalars *gs = p.scal + env;
+    if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
+    if (lane == 0) {
+        wv.wsc->sum_bitrate_running = gs->sum_bitrate_running;
+        wv.wsc->episodes_done = gs->episodes_done;
+        wv.wsc->n_running = gs->n_running;
+        wv.wsc->q_overflow = gs->q_overflow;
+        wv.wsc->g_thr = gs->g_throughput; wv.wsc->g_comp = gs->g_compactness; wv.wsc->g_lu = gs->g_last_update;
+        wv.wsc->req_arrival = gs->req_arrival; wv.wsc->req_holding = gs->req_holding;
+    }
+    // wave-uniform working copies
+    double current_time = gs->current_time;
+    double comp_cur = 1.0;  // _get_network_compactness() of the current occupancy
+    int sum_sh = gs->sum_slots_hops;
+    int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
+    int mt_idx = gs->mt_idx, new_service = gs->new_service;
+    int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     wave_sync();
 
     int sum_span = 0, sum_gaps = 0;
-    if (NET) link_stats_update<W, false>(wv, p, nullptr, 0, E, 0.0, sum_span, sum_gaps);
-
-    // wave-uniform working copies
-    double current_time = sc.current_time;
-    double req_arrival = sc.req_arrival, req_holding = sc.req_holding;
-    double g_thr = sc.g_throughput, g_comp = sc.g_compactness, g_lu = sc.g_last_update;
-    long long c_proc = sc.c[0], c_acc = sc.c[1], c_eproc = sc.c[2], c_eacc = sc.c[3];
-    long long c_req = sc.c[4], c_prov = sc.c[5], c_ereq = sc.c[6], c_eprov = sc.c[7];
-    long long sum_br = sc.sum_bitrate_running, episodes_done = sc.episodes_done;
-    int sum_sh = sc.sum_slots_hops, n_running = sc.n_running;
-    int req_src = sc.req_src, req_dst = sc.req_dst, req_br = sc.req_br, req_sid = sc.req_sid;
-    int mt_idx = sc.mt_idx, new_service = sc.new_service, q_overflow = sc.q_overflow;
+    if (NET) {
+        link_stats_update<W, false, false>(wv, tb, S, E, nullptr, E, 0.0, sum_span, sum_gaps, comp_cur, sum_sh, 0.0);
+        comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
+    }
 
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
-        bool done = false;
         if (p.mode == ORLG_MODE_STEP) {
             // ========================================================== policy: pick (path, slot)
-            const int base = p.pair_base[req_src * N + req_dst];
+            const int base = tb.pair_base[req_src * N + req_dst];
             // (path, word) lanes: AND over the links of candidate path pp
             const int pp = lane / W, pw = lane - pp * W;
             u64 acc = 0ull;
-            if (pp < K) acc = path_word<W>(wv, p.recs, base + pp, pw);
+            if (pp < K) acc = path_word<W>(wv.occ, tb.recs, base + pp, pw);
             int my_se = 0;
-            if (lane < K) my_se = reinterpret_cast<const uint8_t *>(p.recs + base + lane)[1];
-            int my_n = p.nslots_tab[req_br * ORLG_NSLOT_STRIDE + my_se];  // get_number_slots per candidate
+            if (lane < K) my_se = tb.recs[base + lane].se;
+            int my_n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + my_se];  // get_number_slots per candidate
 
             int a_path = K, a_slot = S;  // rejection (rmsa_env.py:871,913)
             const int policy = p.policy;
             if (policy == ORLG_POLICY_EXT) {
-                a_path = uni(p.actions[2 * env]);
-                a_slot = uni(p.actions[2 * env + 1]);
+                const int32_t *acts = kernarg_params()->actions;
+                a_path = uni(acts[2 * env]);
+                a_slot = uni(acts[2 * env + 1]);
             } else if (policy == ORLG_POLICY_DEEP_EXT) {
-                int a = uni(p.actions[env]);
+                int a = uni(kernarg_params()->actions[env]);
                 if (a >= 0 && a < K * p.j) {
                     int route = a / p.j, blk = a - route * p.j;
                     u64 x[W];
@@ -435,7 +539,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
                     if (s0 >= 0) { a_path = route; a_slot = s0; }
                 }
             } else {
-                long long max_free = 0;
+                int max_free = 0;
                 const int kmax = (policy == ORLG_POLICY_SP || policy == ORLG_POLICY_DEEP_SP) ? 1 : K;
                 for (int idp = 0; idp < kmax; ++idp) {
                     u64 x[W];
@@ -450,7 +554,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
                         int s0 = first_fit<W>(x, n, S - n, lane);  // NOTE exclusive bound S - n
                         if (s0 >= 0) {
                             if (policy == ORLG_POLICY_LLP) {
-                                long long fs = 0;
+                                int fs = 0;
 #pragma unroll
                                 for (int w = 0; w < W; ++w) fs += popc64(x[w]);
                                 if (fs > max_free) { a_path = idp; a_slot = s0; max_free = fs; }
@@ -464,8 +568,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
             }
 
             // ========================================================== RMSAEnv.step (rmsa_env.py:222-341)
-            double prev_compact = 1.0, cur_compact = 1.0;
-            if (NET) prev_compact = network_compactness(sum_span, sum_sh, sum_gaps, E);
+            const double prev_compact = comp_cur;
             bool accepted = false;
             if (a_path >= 0 && a_path < K && a_slot >= 0 && a_slot < S) {
                 u64 x[W];
@@ -475,31 +578,30 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
                 if (window_free<W>(x, a_slot, n, S)) {
                     // ---- _provision_path (rmsa_env.py:462-513)
                     const int gid = base + a_path;
-                    const uint8_t *rb = reinterpret_cast<const uint8_t *>(p.recs + gid);
-                    const int hops = rb[0];
-                    apply_window<W>(wv, p.recs, gid, hops, a_slot, n, false);
-                    n_running += 1;
+                    const OrlgPathRec *rec = tb.recs + gid;
+                    const int hops = rec->hops;
+                    apply_window<W>(wv, rec->link, hops, a_slot, n, false);
                     sum_sh += n * hops;
-                    const int br_val = p.bit_rates[req_br];
-                    sum_br += br_val;
-                    if (NET) {
-                        if (FULL) link_stats_update<W, true>(wv, p, rb + 2, 0, hops, current_time, sum_span, sum_gaps);
-                        else link_stats_update<W, false>(wv, p, rb + 2, 0, hops, current_time, sum_span, sum_gaps);
-                        // _update_network_stats (rmsa_env.py:537-560)
-                        double time_diff = current_time - g_lu;
-                        if (current_time > 0) {
-                            double cur_thr = (double)sum_br;
-                            g_thr = ((g_thr * g_lu) + (cur_thr * time_diff)) / current_time;
-                            double cc = network_compactness(sum_span, sum_sh, sum_gaps, E);
-                            g_comp = ((g_comp * g_lu) + (cc * time_diff)) / current_time;
-                        }
-                        g_lu = current_time;
+                    const int br_val = tb.bit_rates[req_br];
+                    double cur_thr = 0.0;
+                    if (lane == 0) {
+                        OrlgWaveScalars *ws = wv.wsc;
+                        ws->n_running += 1;
+                        ws->sum_bitrate_running += br_val;
+                        ws->c[1] += 1; ws->c[3] += 1; ws->c[5] += br_val; ws->c[7] += br_val;
+                        wv.hist[NBR + req_br] += 1;
+                        wv.hist[3 * NBR + req_br] += 1;
                     }
-                    c_acc += 1; c_eacc += 1; c_prov += br_val; c_eprov += br_val;
-                    if (lane == 0) { wv.hist[NBR + req_br] += 1; wv.hist[3 * NBR + req_br] += 1; }
+                    if (NET) {
+                        wave_sync();
+                        cur_thr = (double)wv.wsc->sum_bitrate_running;
+                        // per-link stats of the path's links, then _update_network_stats (rmsa_env.py:494-499)
+                        link_stats_update<W, FULL, true>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
+                                                         comp_cur, sum_sh, cur_thr);
+                    }
                     accepted = true;
                     // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
-                    double rel = req_arrival + req_holding;
+                    double rel = wv.wsc->req_arrival + wv.wsc->req_holding;
                     bool placed = false;
                     for (int q0 = 0; q0 < Q && !placed; q0 += 64) {
                         u64 m = ballot(__double_as_longlong(wv.qtime[q0 + lane]) == (long long)ORLG_INF_BITS);
@@ -512,39 +614,49 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
                             placed = true;
                         }
                     }
-                    if (!placed) q_overflow = 1;
+                    if (!placed && lane == 0) wv.wsc->q_overflow = 1;
                     wave_sync();
                 }
             }
-            if (NET) cur_compact = network_compactness(sum_span, sum_sh, sum_gaps, E);
 
             // per-step outputs (lane 0; consecutive envs are consecutive addresses)
-            const size_t o = (size_t)t * p.B + env;
-            if (lane == 0) {
-                if (p.o_path) p.o_path[o] = a_path;
-                if (p.o_slot) p.o_slot[o] = a_slot;
-                if (p.o_accepted) p.o_accepted[o] = accepted ? 1 : 0;
-                if (p.o_reward) p.o_reward[o] = p.reward_mode == 1 ? (accepted ? 1.0 : -1.0) : (accepted ? 1.0 : 0.0);
-                if (p.o_request) {
-                    int4 r = make_int4(req_sid, req_src, req_dst, p.bit_rates[req_br]);
-                    reinterpret_cast<int4 *>(p.o_request)[o] = r;
+            if (p.out_mask) {
+                const size_t o = (size_t)t * p.B + env;
+                if (lane == 0) {
+                    const int om = p.out_mask;
+                    if (om & (1 << ORLG_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_PATH])[o] = a_path;
+                    if (om & (1 << ORLG_OUT_SLOT)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
+                    if (om & (1 << ORLG_OUT_ACCEPTED)) reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
+                    if (om & (1 << ORLG_OUT_REWARD))
+                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_REWARD])[o] =
+                            p.reward_mode == 1 ? (accepted ? 1.0 : -1.0) : (accepted ? 1.0 : 0.0);
+                    if (om & (1 << ORLG_OUT_REQUEST))
+                        reinterpret_cast<int4 *>(tb.outs[ORLG_OUT_REQUEST])[o] =
+                            make_int4(req_sid, req_src, req_dst, tb.bit_rates[req_br]);
+                    if (om & (1 << ORLG_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_ARRIVAL])[o] = wv.wsc->req_arrival;
+                    if (om & (1 << ORLG_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_HOLDING])[o] = wv.wsc->req_holding;
+                    if (om & (1 << ORLG_OUT_COMPACT)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
+                    if (om & (1 << ORLG_OUT_COMPACT_DIFF))
+                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
                 }
-                if (p.o_arrival) p.o_arrival[o] = req_arrival;
-                if (p.o_holding) p.o_holding[o] = req_holding;
-                if (p.o_compact) p.o_compact[o] = cur_compact;
-                if (p.o_compact_diff) p.o_compact_diff[o] = prev_compact - cur_compact;
             }
             new_service = 0;
         } else if (p.mode == ORLG_MODE_EPISODE_RESET) {
             // reset(only_episode_counters=True) (rmsa_env.py:343-389)
-            c_eproc = 0; c_eacc = 0; c_ereq = 0; c_eprov = 0;
             for (int i = lane; i < NBR; i += 64) { wv.hist[2 * NBR + i] = 0; wv.hist[3 * NBR + i] = 0; }
             wave_sync();
-            if (new_service) {
-                c_eproc += 1;
-                c_ereq += p.bit_rates[req_br];
-                if (lane == 0) wv.hist[2 * NBR + req_br] += 1;
+            eproc = 0;
+            if (lane == 0) {
+                OrlgWaveScalars *ws = wv.wsc;
+                ws->c[2] = 0; ws->c[3] = 0; ws->c[6] = 0; ws->c[7] = 0;
+                if (new_service) {
+                    ws->c[2] = 1;
+                    ws->c[6] = tb.bit_rates[req_br];
+                    wv.hist[2 * NBR + req_br] += 1;
+                }
             }
+            if (new_service) eproc = 1;
+            wave_sync();
         }
 
         // ============================================================== _next_service (rmsa_env.py:643-695)
@@ -558,17 +670,24 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
             double at = current_time + readlane_d(ex, 0);
             double ht = readlane_d(ex, 2);
             current_time = at;
-            int src = choice_cum(p.src_cum, N, u[2], lane);
-            int dst = choice_cum(p.dst_cum + (size_t)src * N, N, u[3], lane);
-            int bri = choice_cum(p.br_cum, NBR, u[4], lane);
-            req_sid = (int)c_eproc;
-            req_src = src; req_dst = dst; req_br = bri; req_arrival = at; req_holding = ht;
+            int src = choice_cum(tb.src_cum, N, u[2], lane);
+            int dst = choice_cum(tb.dst_cum + src * N, N, u[3], lane);
+            int bri = choice_cum(tb.br_cum, NBR, u[4], lane);
+            req_sid = eproc;
+            req_src = src; req_dst = dst; req_br = bri;
             new_service = 1;
-            const int br_val = p.bit_rates[bri];
-            c_proc += 1; c_eproc += 1; c_req += br_val; c_ereq += br_val;
-            if (lane == 0) { wv.hist[bri] += 1; wv.hist[2 * NBR + bri] += 1; }
+            eproc += 1;
+            if (lane == 0) {
+                const int br_val = tb.bit_rates[bri];
+                OrlgWaveScalars *ws = wv.wsc;
+                ws->req_arrival = at; ws->req_holding = ht;
+                ws->c[0] += 1; ws->c[2] += 1; ws->c[4] += br_val; ws->c[6] += br_val;
+                wv.hist[bri] += 1;
+                wv.hist[2 * NBR + bri] += 1;
+            }
 
             // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
+            bool released = false;
             for (;;) {
                 double best_t = 0.0;
                 int best_q = -1;
@@ -586,33 +705,39 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
                 // ---- _release_path (rmsa_env.py:515-535)
                 const uint32_t d = wv.qdesc[best_q];
                 const int gid = (int)(d & 0x3fff), s0 = (int)((d >> 14) & 0x3ff), bri2 = (int)(d >> 24);
-                const uint8_t *rb = reinterpret_cast<const uint8_t *>(p.recs + gid);
-                const int hops = rb[0], se = rb[1];
-                const int n = p.nslots_tab[bri2 * ORLG_NSLOT_STRIDE + se];
-                if (lane == 0) wv.qtime[best_q] = __longlong_as_double((long long)ORLG_INF_BITS);
-                apply_window<W>(wv, p.recs, gid, hops, s0, n, true);
-                n_running -= 1;
-                sum_sh -= n * hops;
-                sum_br -= p.bit_rates[bri2];
-                if (NET) {
-                    if (FULL) link_stats_update<W, true>(wv, p, rb + 2, 0, hops, current_time, sum_span, sum_gaps);
-                    else link_stats_update<W, false>(wv, p, rb + 2, 0, hops, current_time, sum_span, sum_gaps);
+                const OrlgPathRec *rec = tb.recs + gid;
+                const int hops = rec->hops, se = rec->se;
+                const int n = tb.nslots[bri2 * ORLG_NSLOT_STRIDE + se];
+                if (lane == 0) {
+                    wv.qtime[best_q] = __longlong_as_double((long long)ORLG_INF_BITS);
+                    wv.wsc->n_running -= 1;
+                    wv.wsc->sum_bitrate_running -= tb.bit_rates[bri2];
                 }
+                apply_window<W>(wv, rec->link, hops, s0, n, true);
+                sum_sh -= n * hops;
+                if (NET)
+                    link_stats_update<W, FULL, false>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
+                                                      comp_cur, sum_sh, 0.0);
+                released = true;
             }
+            if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
         }
 
         if (p.mode == ORLG_MODE_STEP) {
-            done = (c_eproc == (long long)p.episode_length);
-            if (lane == 0 && p.o_done) p.o_done[(size_t)t * p.B + env] = done ? 1 : 0;
+            const bool done = (eproc == p.episode_length);
+            if (lane == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
+                reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
             if (done && p.auto_reset) {
                 // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
-                episodes_done += 1;
-                c_eacc = 0; c_eprov = 0;
-                c_eproc = 1;
-                c_ereq = p.bit_rates[req_br];
                 for (int i = lane; i < NBR; i += 64) { wv.hist[2 * NBR + i] = 0; wv.hist[3 * NBR + i] = 0; }
                 wave_sync();
-                if (lane == 0) wv.hist[2 * NBR + req_br] = 1;
+                eproc = 1;
+                if (lane == 0) {
+                    OrlgWaveScalars *ws = wv.wsc;
+                    ws->episodes_done += 1;
+                    ws->c[2] = 1; ws->c[3] = 0; ws->c[6] = tb.bit_rates[req_br]; ws->c[7] = 0;
+                    wv.hist[2 * NBR + req_br] = 1;
+                }
                 wave_sync();
             }
         }
@@ -621,31 +746,33 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_rmsa_ker
     // ------------------------------------------------------------------ LDS -> HBM (coalesced)
     wave_sync();
     {
-        u64 *g = p.occ + (size_t)env * NW;
+        KernargParams kp = kernarg_params();
+        u64 *g = kp->occ + (size_t)env * NW;
         for (int i = lane; i < NW; i += 64) g[i] = wv.occ[i];
-        double *gq = p.qtime + (size_t)env * Q;
-        uint32_t *gd = p.qdesc + (size_t)env * Q;
+        double *gq = kp->qtime + (size_t)env * Q;
+        uint32_t *gd = kp->qdesc + (size_t)env * Q;
         for (int i = lane; i < Q; i += 64) { gq[i] = wv.qtime[i]; gd[i] = wv.qdesc[i]; }
-        uint32_t *gm = p.mt + (size_t)env * ORLG_MT_N;
+        uint32_t *gm = kp->mt + (size_t)env * ORLG_MT_N;
         for (int i = lane; i < ORLG_MT_N; i += 64) gm[i] = wv.mt[i];
         if (FULL) {
-            double *gl = p.lstat + (size_t)env * 4 * E;
+            double *gl = kp->lstat + (size_t)env * 4 * E;
             for (int i = lane; i < 4 * E; i += 64) gl[i] = wv.lst[i];
         }
-        int32_t *gh = p.hist + (size_t)env * 4 * NBR;
+        int32_t *gh = kp->hist + (size_t)env * 4 * NBR;
         for (int i = lane; i < 4 * NBR; i += 64) gh[i] = wv.hist[i];
-    }
-    if (lane == 0) {
-        sc.current_time = current_time;
-        sc.req_arrival = req_arrival; sc.req_holding = req_holding;
-        sc.g_throughput = g_thr; sc.g_compactness = g_comp; sc.g_last_update = g_lu;
-        sc.c[0] = c_proc; sc.c[1] = c_acc; sc.c[2] = c_eproc; sc.c[3] = c_eacc;
-        sc.c[4] = c_req; sc.c[5] = c_prov; sc.c[6] = c_ereq; sc.c[7] = c_eprov;
-        sc.sum_bitrate_running = sum_br; sc.episodes_done = episodes_done;
-        sc.sum_slots_hops = sum_sh; sc.n_running = n_running;
-        sc.req_src = req_src; sc.req_dst = req_dst; sc.req_br = req_br; sc.req_sid = req_sid;
-        sc.mt_idx = mt_idx; sc.new_service = new_service; sc.q_overflow = q_overflow;
-        p.scal[env] = sc;
+        OrlgEnvScalars *go = kp->scal + env;
+        const OrlgWaveScalars *ws = wv.wsc;
+        if (lane < 8) go->c[lane] = ws->c[lane];
+        if (lane == 0) {
+            go->current_time = current_time;
+            go->req_arrival = ws->req_arrival; go->req_holding = ws->req_holding;
+            go->g_throughput = ws->g_thr; go->g_compactness = ws->g_comp; go->g_last_update = ws->g_lu;
+            go->sum_bitrate_running = ws->sum_bitrate_running;
+            go->episodes_done = ws->episodes_done;
+            go->sum_slots_hops = sum_sh; go->n_running = ws->n_running;
+            go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
+            go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
+        }
     }
 }
 
@@ -656,36 +783,33 @@ template <int W>
 __global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgParams p, int env, u64 *masks,
                                                                     int32_t *nslots) {
     extern __shared__ __align__(16) unsigned char smem[];
+    stage_tables(smem, p);
+    const Tab tb = make_tab(smem, p);
     const int lane = threadIdx.x & 63;
-    Wave wv;
-    wv.lane = lane;
-    wv.occ = reinterpret_cast<u64 *>(smem);
+    u64 *occ = reinterpret_cast<u64 *>(smem + p.l_shared_bytes);
     const u64 *g = p.occ + (size_t)env * p.NW;
-    for (int i = lane; i < p.NW; i += 64) wv.occ[i] = g[i];
+    for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
     wave_sync();
     const OrlgEnvScalars *sc = p.scal + env;
-    const int base = p.pair_base[sc->req_src * p.N + sc->req_dst];
+    const int base = tb.pair_base[sc->req_src * p.N + sc->req_dst];
     const int pp = lane / W, pw = lane - pp * W;
-    if (pp < p.K) masks[pp * W + pw] = path_word<W>(wv, p.recs, base + pp, pw);
-    if (lane < p.K) {
-        int se = reinterpret_cast<const uint8_t *>(p.recs + base + lane)[1];
-        nslots[lane] = p.nslots_tab[sc->req_br * ORLG_NSLOT_STRIDE + se];
-    }
+    if (pp < p.K) masks[pp * W + pw] = path_word<W>(occ, tb.recs, base + pp, pw);
+    if (lane < p.K) nslots[lane] = tb.nslots[sc->req_br * ORLG_NSLOT_STRIDE + tb.recs[base + lane].se];
 }
 
 // DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env; one wave per env.
 template <int W>
-__global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_deeprmsa_obs_kernel(const OrlgParams p) {
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deeprmsa_obs_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
+    stage_tables(smem, p);
+    const Tab tb = make_tab(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
-    const int env = blockIdx.x * ORLG_WAVES_PER_BLOCK + wib;
+    const int env = blockIdx.x * (int)(blockDim.x >> 6) + wib;
     if (env >= p.B) return;
-    Wave wv;
-    wv.lane = lane;
-    wv.occ = reinterpret_cast<u64 *>(smem + (size_t)wib * ((p.NW * 8 + 15) & ~15));
+    u64 *occ = reinterpret_cast<u64 *>(smem + p.l_shared_bytes + (size_t)wib * ((p.NW * 8 + 15) & ~15));
     const u64 *g = p.occ + (size_t)env * p.NW;
-    for (int i = lane; i < p.NW; i += 64) wv.occ[i] = g[i];
+    for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
     wave_sync();
     const OrlgEnvScalars *sc = p.scal + env;
     const int N = p.N, K = p.K, S = p.S, J = p.j;
@@ -693,15 +817,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_WAVES_PER_BLOCK) void orlg_deeprmsa
     double *out = p.o_obs + (size_t)env * p.obs_dim;
     const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
     // bit rate + one-hot endpoints
-    if (lane == 0) out[0] = (double)p.bit_rates[br] / 100;
+    if (lane == 0) out[0] = (double)tb.bit_rates[br] / 100;
     for (int i = lane; i < 2 * N; i += 64) out[1 + i] = (i == mn || i == N + mx) ? 1.0 : 0.0;
-    const int base = p.pair_base[src * N + dst];
+    const int base = tb.pair_base[src * N + dst];
     const int pp = lane / W, pw = lane - pp * W;
     u64 acc = 0ull;
-    if (pp < K) acc = path_word<W>(wv, p.recs, base + pp, pw);
+    if (pp < K) acc = path_word<W>(occ, tb.recs, base + pp, pw);
     int my_se = 0;
-    if (lane < K) my_se = reinterpret_cast<const uint8_t *>(p.recs + base + lane)[1];
-    int my_n = p.nslots_tab[br * ORLG_NSLOT_STRIDE + my_se];
+    if (lane < K) my_se = tb.recs[base + lane].se;
+    int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
     const int PW = 2 * J + 3;
     double *sp = out + 1 + 2 * N;
     for (int idp = 0; idp < K; ++idp) {
