@@ -263,16 +263,22 @@ DEV bool window_free(const u64 (&x)[W], int s, int n, int S) {
     return ok;
 }
 
-DEV int rec_byte(u64 lo, u64 hi, int i) { return (int)(((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)))) & 0xffull); }
-
-// AND of the link bitmaps of path record `gid` for word w (get_available_slots, rmsa_env.py:745-756)
+// AND of the link bitmaps of path record `gid` for word w (get_available_slots, rmsa_env.py:745-756).
+// `active` lanes hold a valid (gid, w); the hop loop is fully unrolled over the 16-byte record with
+// compile-time byte positions (v_bfe_u32 + v_mad_u32_u24 per hop) and leaves as soon as no lane has hops left.
 template <int W>
-DEV u64 path_word(const u64 *occ, const OrlgPathRec *recs, int gid, int w) {
-    const u64 *rp = reinterpret_cast<const u64 *>(recs + gid);
-    u64 lo = rp[0], hi = rp[1];
-    int hops = (int)(lo & 0xff);
-    u64 acc = ~0ull;
-    for (int h = 0; h < hops; ++h) acc &= occ[rec_byte(lo, hi, 2 + h) * W + w];
+DEV u64 path_word(const u64 *occ, const OrlgPathRec *recs, int gid, int w, bool active) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (active) r = *reinterpret_cast<const uint4 *>(recs + gid);
+    const uint32_t q[4] = {r.x, r.y, r.z, r.w};
+    const int hops = (int)(r.x & 0xffu);  // 0 on inactive lanes
+    u64 acc = active ? ~0ull : 0ull;
+#pragma unroll
+    for (int h = 0; h < ORLG_MAX_HOPS; ++h) {
+        if (ballot(h < hops) == 0ull) break;
+        const int link = (int)((q[(h + 2) >> 2] >> (8 * ((h + 2) & 3))) & 0xffu);
+        if (h < hops) acc &= occ[__mul24(link, W) + w];
+    }
     return acc;
 }
 
@@ -313,7 +319,7 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
         // ---- phase A: (link, word) lanes
         if (hl < nl) {
             int link = links ? (int)links[h0 + hl] : h0 + hl;
-            const u64 *row = wv.occ + link * W;
+            const u64 *row = wv.occ + __mul24(link, W);
             u64 x = row[w];
             u64 prev = w > 0 ? row[w - 1] : 0ull;
             u64 u = ~x & valid_mask(S, w);
@@ -355,7 +361,7 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
             link = links ? (int)links[h0 + lane] : h0 + lane;
 #pragma unroll
             for (int q = 0; q < W; ++q) {
-                const uint32_t *sc = wv.scratch + (lane * W + q) * 4;
+                const uint32_t *sc = wv.scratch + (__mul24(lane, W) + q) * 4;
                 uint32_t a = sc[0], b = sc[1], c = sc[2];
                 freec += (int)(a & 0xffff);
                 F += (int)(a >> 16);
@@ -432,7 +438,7 @@ DEV void apply_window(Wave &wv, const uint8_t *links, int hops, int s, int n, bo
     for (int h0 = 0; h0 < hops; h0 += HPC) {
         int h = h0 + hl;
         if (hl < HPC && h < hops && m) {
-            u64 *word = wv.occ + (int)links[h] * W + w;
+            u64 *word = wv.occ + __mul24((int)links[h], W) + w;
             *word = set_free ? (*word | m) : (*word & ~m);
         }
     }
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             // (path, word) lanes: AND over the links of candidate path pp
             const int pp = lane / W, pw = lane - pp * W;
             u64 acc = 0ull;
-            if (pp < K) acc = path_word<W>(wv.occ, tb.recs, base + pp, pw);
+            acc = path_word<W>(wv.occ, tb.recs, base + pp, pw, pp < K);
             int my_se = 0;
             if (lane < K) my_se = tb.recs[base + lane].se;
             int my_n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + my_se];  // get_number_slots per candidate
@@ -793,7 +799,10 @@ __global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgPa
     const OrlgEnvScalars *sc = p.scal + env;
     const int base = tb.pair_base[sc->req_src * p.N + sc->req_dst];
     const int pp = lane / W, pw = lane - pp * W;
-    if (pp < p.K) masks[pp * W + pw] = path_word<W>(occ, tb.recs, base + pp, pw);
+    {
+        u64 m = path_word<W>(occ, tb.recs, base + pp, pw, pp < p.K);
+        if (pp < p.K) masks[pp * W + pw] = m;
+    }
     if (lane < p.K) nslots[lane] = tb.nslots[sc->req_br * ORLG_NSLOT_STRIDE + tb.recs[base + lane].se];
 }
 
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
     const int base = tb.pair_base[src * N + dst];
     const int pp = lane / W, pw = lane - pp * W;
     u64 acc = 0ull;
-    if (pp < K) acc = path_word<W>(occ, tb.recs, base + pp, pw);
+    acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
     int my_se = 0;
     if (lane < K) my_se = tb.recs[base + lane].se;
     int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
