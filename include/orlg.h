@@ -101,6 +101,8 @@ typedef struct orlg_step_io {
     double *holding;     /* its holding_time */
     double *network_compactness;            /* info["network_compactness"] */
     double *network_compactness_difference; /* info["network_compactness_difference"] */
+    double *avg_link_compactness;           /* info["avg_link_compactness"]  (stats level FULL) */
+    double *avg_link_utilization;           /* info["avg_link_utilization"]  (stats level FULL) */
 } orlg_step_io;
 
 /* counters of one env, rmsa_env.py:84-87 + optical_network_env.py:35-38 */
@@ -162,6 +164,9 @@ int orlg_get_episodes_done(orlg_env *env, int64_t *out /* [B] */);
  * paths of env_index's pending request, the AND of the free-slot bitmaps of its links.
  * masks: [k][W] uint64 (host or device), nslots: [k] int32 = get_number_slots(path). */
 int orlg_query_path_masks(orlg_env *env, int32_t env_index, uint64_t *masks, int32_t *nslots);
+/* the same for ONE arbitrary path record (any Path object a heuristic passes to is_path_free /
+ * get_available_slots): mask [W] uint64, nslots [1] = get_number_slots for the pending bit rate */
+int orlg_query_path_mask(orlg_env *env, int32_t env_index, int32_t path_gid, uint64_t *mask, int32_t *nslots);
 
 /* DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env: [B][1 + 2N + (2j+3)k] float64 */
 int orlg_deeprmsa_observation(orlg_env *env, double *out);

@@ -1,7 +1,13 @@
-from . import _lib
+from . import _lib, envs
 from ._lib import OrlgError
 from .batched import DEFAULT_BIT_RATES, BatchedDeepRMSAEnv, BatchedRMSAEnv
+from .envs import (DeepRMSAEnv, RMSAEnv, deeprmsa_shortest_available_path_first_fit,
+                   deeprmsa_shortest_path_first_fit, evaluate_heuristic, least_loaded_path_first_fit,
+                   random_policy, shortest_available_path_first_fit, shortest_path_first_fit)
 from .topology import FrozenTopology, Modulation, Path, Service, TopologyView, selection_tables
 
 __all__ = ["FrozenTopology", "Modulation", "Path", "Service", "TopologyView", "selection_tables",
-           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib"]
+           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
+           "RMSAEnv", "DeepRMSAEnv", "shortest_path_first_fit", "shortest_available_path_first_fit",
+           "least_loaded_path_first_fit", "deeprmsa_shortest_path_first_fit",
+           "deeprmsa_shortest_available_path_first_fit", "random_policy", "evaluate_heuristic"]

@@ -39,13 +39,15 @@ class RmsaConfig(C.Structure):
 
 class StepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_path", "act_slot", "accepted", "done", "reward", "request", "arrival",
-                                         "holding", "network_compactness", "network_compactness_difference")]
+                                         "holding", "network_compactness", "network_compactness_difference",
+                                         "avg_link_compactness", "avg_link_utilization")]
 
 
 # numpy dtypes of the step outputs
 STEP_IO_DTYPES = {"act_path": "int32", "act_slot": "int32", "accepted": "uint8", "done": "uint8", "reward": "float64",
                   "request": "int32", "arrival": "float64", "holding": "float64", "network_compactness": "float64",
-                  "network_compactness_difference": "float64"}
+                  "network_compactness_difference": "float64", "avg_link_compactness": "float64",
+                  "avg_link_utilization": "float64"}
 
 _lib = None
 
@@ -83,6 +85,7 @@ def load(build_if_missing=True):
     L.orlg_get_num_running.argtypes = [vp, vp]
     L.orlg_get_episodes_done.argtypes = [vp, vp]
     L.orlg_query_path_masks.argtypes = [vp, i32, vp, vp]
+    L.orlg_query_path_mask.argtypes = [vp, i32, i32, vp, vp]
     L.orlg_deeprmsa_observation.argtypes = [vp, vp]
     L.orlg_deeprmsa_obs_dim.argtypes = [vp]
     L.orlg_reduce_counters.argtypes = [vp, vp]
@@ -97,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "orlg_synchronize", "orlg_reset", "orlg_step", "orlg_get_requests", "orlg_get_counters",
     "orlg_get_current_time", "orlg_get_occupancy", "orlg_words_per_link", "orlg_get_link_stats",
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
-    "orlg_query_path_masks", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
+    "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
     "orlg_host_log",
 ]
 

@@ -226,6 +226,13 @@ class BatchedRMSAEnv:
         _lib.check(self.L.orlg_query_path_masks(self.h, int(env_index), _ptr(m), _ptr(n)))
         return m, n
 
+    def path_mask(self, path_gid: int, env_index: int = 0):
+        """Free bitmap [W] of one arbitrary path record and its slot demand for the pending bit rate."""
+        m = np.zeros(self.words_per_link, np.uint64)
+        n = np.zeros(1, np.int32)
+        _lib.check(self.L.orlg_query_path_mask(self.h, int(env_index), int(path_gid), _ptr(m), _ptr(n)))
+        return m, int(n[0])
+
     def observation(self, out=None):
         """DeepRMSAEnv.observation() for every env: [B, obs_dim] float64."""
         if out is None:

@@ -196,7 +196,7 @@ static rmsa_kernel_t pick_obs(int W) {
         default: return nullptr;
     }
 }
-typedef void (*masks_kernel_t)(const OrlgParams, int, u64 *, int32_t *);
+typedef void (*masks_kernel_t)(const OrlgParams, int, int, int, u64 *, int32_t *);
 static masks_kernel_t pick_masks(int W) {
     switch (W) {
         case 1: return orlg_path_masks_kernel<1>;
@@ -516,7 +516,8 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
         {io ? io->act_path : nullptr, 4},   {io ? io->act_slot : nullptr, 4},  {io ? io->accepted : nullptr, 1},
         {io ? io->done : nullptr, 1},       {io ? io->reward : nullptr, 8},    {io ? io->request : nullptr, 16},
         {io ? io->arrival : nullptr, 8},    {io ? io->holding : nullptr, 8},   {io ? io->network_compactness : nullptr, 8},
-        {io ? io->network_compactness_difference : nullptr, 8}};
+        {io ? io->network_compactness_difference : nullptr, 8},
+        {io ? io->avg_link_compactness : nullptr, 8},   {io ? io->avg_link_utilization : nullptr, 8}};
     bool staged[ORLG_NUM_OUTS] = {false};
     p.out_mask = 0;
     for (int i = 0; i < ORLG_NUM_OUTS; i++) {
@@ -627,22 +628,35 @@ int orlg_get_episodes_done(orlg_env *e, int64_t *out) {
     return rc ? rc : copy_out(e, out, e->staging, bytes);
 }
 
-int orlg_query_path_masks(orlg_env *e, int32_t env_index, uint64_t *masks, int32_t *nslots) {
+static int query_masks(orlg_env *e, int32_t env_index, int gid0, int count, uint64_t *masks, int32_t *nslots) {
     if (!e || !masks || !nslots) return fail(ORLG_ERR_INVALID, "null argument");
     if (env_index < 0 || env_index >= e->p.B) return fail(ORLG_ERR_INVALID, "env_index out of range");
     HIP_TRY(hipSetDevice(e->device));
-    size_t mbytes = (size_t)e->p.K * e->W * 8, nbytes = (size_t)e->p.K * 4;
+    size_t mbytes = (size_t)count * e->W * 8, nbytes = (size_t)count * 4;
     int rc = ensure_staging(e, mbytes + nbytes + 64);
     if (rc) return rc;
     masks_kernel_t k = pick_masks(e->W);
     u64 *dm = reinterpret_cast<u64 *>(e->staging);
     int32_t *dn = reinterpret_cast<int32_t *>(e->staging + ((mbytes + 15) & ~(size_t)15));
-    hipLaunchKernelGGL(k, dim3(1), dim3(ORLG_WAVE), (size_t)e->p.l_shared_bytes + (size_t)e->p.NW * 8, e->stream, e->p, env_index, dm, dn);
+    size_t lds = (size_t)e->p.l_shared_bytes + (size_t)e->p.NW * 8;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(1), dim3(ORLG_WAVE), lds, e->stream, e->p, env_index, gid0, count, dm, dn);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(masks, dm, mbytes, hipMemcpyDefault, e->stream));
     HIP_TRY(hipMemcpyAsync(nslots, dn, nbytes, hipMemcpyDefault, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return ORLG_OK;
+}
+
+int orlg_query_path_masks(orlg_env *e, int32_t env_index, uint64_t *masks, int32_t *nslots) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    return query_masks(e, env_index, -1, e->p.K, masks, nslots);
+}
+
+int orlg_query_path_mask(orlg_env *e, int32_t env_index, int32_t path_gid, uint64_t *mask, int32_t *nslots) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    if (path_gid < 0 || path_gid >= e->num_paths) return fail(ORLG_ERR_INVALID, "path_gid out of range");
+    return query_masks(e, env_index, path_gid, 1, mask, nslots);
 }
 
 int orlg_deeprmsa_obs_dim(orlg_env *e) { return e ? e->p.obs_dim : ORLG_ERR_INVALID; }

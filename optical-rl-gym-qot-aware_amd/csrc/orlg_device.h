@@ -10,7 +10,7 @@
 #define ORLG_MAX_W 8          // 64-bit words per link: S <= 512
 #define ORLG_MAX_HOPS 14
 #define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
-#define ORLG_NUM_OUTS 10
+#define ORLG_NUM_OUTS 12
 
 // One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
 // "index" of every hop (utils.py:27-36, rmsa_env.py:479-483).
@@ -54,7 +54,8 @@ enum { ORLG_POLICY_EXT = -1, ORLG_POLICY_SP = 0, ORLG_POLICY_SAP = 1, ORLG_POLIC
        ORLG_POLICY_DEEP_SAP = 4, ORLG_POLICY_DEEP_EXT = 5 };
 // per-step output slots (OrlgParams::outs)
 enum { ORLG_OUT_PATH = 0, ORLG_OUT_SLOT, ORLG_OUT_ACCEPTED, ORLG_OUT_DONE, ORLG_OUT_REWARD, ORLG_OUT_REQUEST,
-       ORLG_OUT_ARRIVAL, ORLG_OUT_HOLDING, ORLG_OUT_COMPACT, ORLG_OUT_COMPACT_DIFF };
+       ORLG_OUT_ARRIVAL, ORLG_OUT_HOLDING, ORLG_OUT_COMPACT, ORLG_OUT_COMPACT_DIFF, ORLG_OUT_AVG_LINK_COMPACT,
+       ORLG_OUT_AVG_LINK_UTIL };
 
 // Kernel parameters (passed by value).
 struct OrlgParams {

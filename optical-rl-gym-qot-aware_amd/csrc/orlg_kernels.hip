@@ -282,6 +282,43 @@ DEV u64 path_word(const u64 *occ, const OrlgPathRec *recs, int gid, int w, bool 
     return acc;
 }
 
+// numpy's float64 add.reduce order (pairwise_sum in numpy/core/src/umath/loops_utils.h.src: 8 running
+// accumulators, fixed combination tree, blocks of <= 128) so that np.mean(...) in the info dict is reproduced
+// bit for bit; n <= 255 here (one link per element).
+DEV double np_pairwise_block(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+DEV double np_pairwise_256(const double *a, int n) {  // n <= 256: at most one split
+    if (n <= 128) return np_pairwise_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_block(a, n2) + np_pairwise_block(a + n2, n - n2);
+}
+DEV double np_mean(const double *a, int n) {  // n <= 512: at most two levels of splitting
+    double s;
+    if (n <= 128) {
+        s = np_pairwise_block(a, n);
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        s = np_pairwise_256(a, n2) + np_pairwise_256(a + n2, n - n2);
+    }
+    return s / (double)n;
+}
+
 // _get_network_compactness (rmsa_env.py:844-851) from the maintained integer sums
 DEV double network_compactness(int sum_span, int sum_slots_hops, int sum_gaps, int E) {
     if (sum_gaps > 0) return ((double)sum_span / (double)sum_slots_hops) * ((double)E / (double)sum_gaps);
@@ -644,6 +681,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                     if (om & (1 << ORLG_OUT_COMPACT)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
                     if (om & (1 << ORLG_OUT_COMPACT_DIFF))
                         reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
+                    // info["avg_link_compactness" | "avg_link_utilization"] (rmsa_env.py:311-322): np.mean over the
+                    // links, taken here -- after the provisioning, before _next_service releases anything
+                    if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_COMPACT)))
+                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(wv.lst + 2 * E, E);
+                    if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_UTIL)))
+                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(wv.lst, E);
                 }
             }
             new_service = 0;
@@ -786,8 +829,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
 // For env `env_index`: the k path-wide free bitmaps of its pending request and get_number_slots per path
 // (rmsa_env.py:708-719, 745-756).  One wave.
 template <int W>
-__global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgParams p, int env, u64 *masks,
-                                                                    int32_t *nslots) {
+__global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgParams p, int env, int gid0, int count,
+                                                                    u64 *masks, int32_t *nslots) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
     const Tab tb = make_tab(smem, p);
@@ -797,13 +840,15 @@ __global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgPa
     for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
     wave_sync();
     const OrlgEnvScalars *sc = p.scal + env;
-    const int base = tb.pair_base[sc->req_src * p.N + sc->req_dst];
+    // gid0 < 0: the k candidate paths of the pending request; otherwise `count` records starting at gid0
+    const int base = gid0 < 0 ? tb.pair_base[sc->req_src * p.N + sc->req_dst] : gid0;
+    const int cnt = gid0 < 0 ? p.K : count;
     const int pp = lane / W, pw = lane - pp * W;
     {
-        u64 m = path_word<W>(occ, tb.recs, base + pp, pw, pp < p.K);
-        if (pp < p.K) masks[pp * W + pw] = m;
+        u64 m = path_word<W>(occ, tb.recs, base + pp, pw, pp < cnt);
+        if (pp < cnt) masks[pp * W + pw] = m;
     }
-    if (lane < p.K) nslots[lane] = tb.nslots[sc->req_br * ORLG_NSLOT_STRIDE + tb.recs[base + lane].se];
+    if (lane < cnt) nslots[lane] = tb.nslots[sc->req_br * ORLG_NSLOT_STRIDE + tb.recs[base + lane].se];
 }
 
 // DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env; one wave per env.

@@ -1,0 +1,104 @@
+"""The single-env gym views (RMSAEnv / DeepRMSAEnv with the reference's object surface) driven by heuristic
+callbacks f(env) -> action, against the reference's golden traces: same actions, rewards, done flags and info
+dict (integer ratios exactly, time-derived floats to rtol 1e-12)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_topology
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rmsa_view_sapff_matches_reference():
+    import optical_rl_gym_amd as pkg
+    z, meta = load_golden("rmsa_nsfnet_s10_sapff")
+    topo = load_topology(meta["topology"])
+    env = pkg.RMSAEnv(topology=topo, **meta["env_kwargs"])
+    assert env.action_space is not None and env.topology.graph["k_paths"] == 5
+    n = 200
+    for t in range(n):
+        s = env.current_service
+        assert (s.source_id, s.destination_id, s.bit_rate, s.service_id) == \
+            (z["src_id"][t], z["dst_id"][t], z["bit_rate"][t], z["service_id"][t])
+        a = pkg.shortest_available_path_first_fit(env)
+        assert a == (z["act_path"][t], z["act_slot"][t]), t
+        obs, reward, done, info = env.step(a)
+        assert reward == z["reward"][t] and done == bool(z["done"][t]) and s.accepted == bool(z["accepted"][t])
+        assert obs["current_service"] is env.current_service
+        # the recorded counters are post-step (they already include the next request); info is built before it
+        proc = int(z["services_processed"][t]) - 1
+        req = int(z["bit_rate_requested"][t]) - int(z["bit_rate"][t + 1])
+        assert info["service_blocking_rate"] == (proc - int(z["services_accepted"][t])) / proc
+        assert info["bit_rate_blocking_rate"] == (req - int(z["bit_rate_provisioned"][t])) / req
+        for key in ("network_compactness", "avg_link_compactness", "avg_link_utilization"):
+            np.testing.assert_allclose(info[key], z[key][t], rtol=1e-11, atol=0, err_msg=f"{key} step {t}")
+        np.testing.assert_allclose(info["network_compactness_difference"], z["network_compactness_difference"][t],
+                                   rtol=1e-9, atol=1e-13)
+        assert info["fairness"] == z["fairness"][t]
+        assert env.services_processed == z["services_processed"][t]
+    assert int(env.topology.graph["available_slots"].sum()) == z["free_total"][n - 1]
+    env.close()
+
+
+@pytest.mark.parametrize("policy", ["sp_ff", "llp_ff"])
+def test_rmsa_view_other_heuristics(policy):
+    import optical_rl_gym_amd as pkg
+    name = {"sp_ff": "rmsa_nsfnet_s10_spff", "llp_ff": "rmsa_nsfnet_s12_llpff"}[policy]
+    fn = {"sp_ff": pkg.shortest_path_first_fit, "llp_ff": pkg.least_loaded_path_first_fit}[policy]
+    z, meta = load_golden(name)
+    env = pkg.RMSAEnv(topology=load_topology(meta["topology"]), **meta["env_kwargs"])
+    for t in range(120):
+        a = fn(env)
+        assert a == (z["act_path"][t], z["act_slot"][t]), t
+        _, reward, _, _ = env.step(a)
+        assert reward == z["reward"][t]
+    env.close()
+
+
+def test_evaluate_heuristic_episodes():
+    """utils.evaluate_heuristic semantics: reset() between episodes of episode_length - 1 steps."""
+    import optical_rl_gym_amd as pkg
+    z, meta = load_golden("rmsa_nsfnet_s10_sapff_reset")
+    env = pkg.RMSAEnv(topology=load_topology(meta["topology"]), **meta["env_kwargs"])
+    rewards, lengths = pkg.evaluate_heuristic(env, pkg.shortest_available_path_first_fit, n_eval_episodes=2,
+                                              return_episode_rewards=True)
+    L = meta["env_kwargs"]["episode_length"]
+    assert lengths == [L - 1, L - 1]
+    assert rewards == [float(z["reward"][:L - 1].sum()), float(z["reward"][L - 1:2 * (L - 1)].sum())]
+    env.close()
+
+
+def test_deeprmsa_view_matches_reference():
+    import optical_rl_gym_amd as pkg
+    z, meta = load_golden("deeprmsa_nsfnet_s10_sapff")
+    env = pkg.DeepRMSAEnv(topology=load_topology(meta["topology"]), **meta["env_kwargs"])
+    assert env.observation_space is not None
+    assert np.array_equal(env.observation(), z["obs0"])
+    for t in range(150):
+        a = pkg.deeprmsa_shortest_available_path_first_fit(env)
+        assert a == z["action"][t], t
+        obs, reward, done, info = env.step(a)
+        assert np.array_equal(obs, z["obs"][t]), t
+        assert reward == z["reward"][t] and done == bool(z["done"][t])
+        if done:
+            env.reset()
+    env.close()
+
+
+def test_path_mask_for_non_candidate_path():
+    """is_path_free / get_available_slots for a Path that is not among the pending request's candidates."""
+    import optical_rl_gym_amd as pkg
+    topo = load_topology("nsfnet_chen_5-paths_6-modulations")
+    env = pkg.RMSAEnv(topology=topo, num_spectrum_resources=320, load=50, mean_service_holding_time=25, seed=3)
+    for _ in range(60):
+        env.step(pkg.shortest_available_path_first_fit(env))
+    avail = env.topology.graph["available_slots"]
+    for (a, b) in (("1", "14"), ("3", "9")):
+        for p in env.k_shortest_paths[a, b]:
+            links = [env.topology[p.node_list[i]][p.node_list[i + 1]]["index"] for i in range(p.hops)]
+            want = np.prod(avail[links, :], axis=0)
+            assert np.array_equal(env.get_available_slots(p), want)
+            n = env.get_number_slots(p)
+            for s in (0, 17, 100, 319 - n, 320 - n):
+                assert env.is_path_free(p, s, n) == bool(want[s:s + n].all())
+    env.close()
