@@ -89,7 +89,8 @@ def main():
 
     topo = load_topology(TOPOLOGY)
     B = args.batch
-    env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=10 + rank * B, stats_level=args.stats, device=local_rank)
+    from optical_rl_gym_amd.distributed import allreduce_stats, shard_base_seed
+    env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=shard_base_seed(10, B, rank), stats_level=args.stats, device=local_rank)
     # a dedicated (non-default) stream: the step kernels AND the timing events live on it
     stream = torch.cuda.Stream(device=dev)
     env.set_stream(stream.cuda_stream)
@@ -123,13 +124,11 @@ def main():
 
     # statistics all-reduce (the path's only collective)
     red, vec = env.reduce_counters()
-    stats = torch.from_numpy(vec.copy()).to(dev)
+    stats = allreduce_stats(vec, dist, dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    stats = stats.cpu().numpy()
 
     if rank == 0:
         W = env.words_per_link
