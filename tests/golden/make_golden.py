@@ -364,6 +364,117 @@ def gen_deeprmsa():
               "obs dim", out["obs"].shape[1])
 
 
+# --------------------------------------------------------------------------- PhyRMSA (QoT-aware) traces
+PHY_TABLES = {
+    # name: (mat file, struct name, topology fixture)
+    "us14_k3": ("Results_K3SP_FRP_SLC_CBG_USB14.mat", "Results_K3SP_FRP_SLC_CBG_USB14", "us14_3-paths_6-modulations"),
+    "jpn12_k3": ("Results_K3SP_FRP_SLC_CBG_JPN12.mat", "Results_K3SP_FRP_SLC_CBG_JPN12", "jpn12_3-paths_6-modulations"),
+}
+
+
+def load_phy_tables(name):
+    from scipy.io import loadmat
+    fname, struct, _ = PHY_TABLES[name]
+    d = loadmat(os.path.join(REF, "examples", "phy_frag_rmsa", "inputs", fname))[struct]
+    return d[0][0][0], d[0][0][1], d[0][0][2]  # connections_detail, modulation_level, gsnr
+
+
+def gen_phy_tables():
+    """QoT tables as flat arrays: (source, destination) node numbers per row, modulation level uint8 and
+    GSNR float64 per (row, channel, k-path) for the first k = 3 path columns (the shipped pickles have k = 3)."""
+    os.makedirs(os.path.join(HERE, "tables"), exist_ok=True)
+    for name in PHY_TABLES:
+        conn, mod, gsnr = load_phy_tables(name)
+        pairs = np.array([[int(np.asarray(r[0]).ravel()[0]), int(np.asarray(r[1]).ravel()[0])] for r in conn], np.int32)
+        np.savez_compressed(os.path.join(HERE, "tables", name + ".npz"), pairs=pairs,
+                            modulation_level=np.ascontiguousarray(mod[:, :, :3]),
+                            gsnr=np.ascontiguousarray(gsnr[:, :, :3]))
+        print("tables", name, pairs.shape, mod.shape, "levels", np.unique(mod[:, :, :3]).tolist())
+
+
+def run_phy_trace(topo, tables, env_kwargs, policy, n_steps, reset_on_done):
+    from optical_rl_gym.envs import phy_rmsa_env as P
+
+    conn, mod, gsnr = tables
+    env = P.PhyRMSAEnv(topology=topo, modulation_level=mod, connections_detail=conn, gsnr=gsnr, **env_kwargs)
+    pol = {"bmfa": P.phy_aware_bmfa_rmsa, "bmfa_rss": P.phy_aware_bmfa_rss_rmsa, "sapff": P.sapff_rmsa,
+           "bmff": P.phy_aware_bmff_rmsa, "sapbm": P.phy_aware_sapbm_rmsa}[policy]
+    rec = Recorder()
+    MAXCH = 12
+    chans, used, free, cap = [], [], [], []
+    for _ in range(n_steps):
+        s = env.current_service
+        a = pol(env)
+        _, reward, done, _, info = env.step(a)
+        row_c, row_u, row_f, row_k = [-1] * MAXCH, [0.0] * MAXCH, [0.0] * MAXCH, [0] * MAXCH
+        assert len(a[1]) <= MAXCH
+        for i, c in enumerate(a[1]):
+            row_c[i], row_u[i], row_f[i], row_k[i] = int(c[0]), float(c[1]), float(c[2]), int(c[3])
+        chans.append(row_c); used.append(row_u); free.append(row_f); cap.append(row_k)
+        av = env.topology.graph["available_channels"]
+        rec.add(
+            service_id=s.service_id, src_id=s.source_id, dst_id=s.destination_id, bit_rate=s.bit_rate,
+            arrival=s.arrival_time, holding=s.holding_time, act_path=int(a[0]), n_channels=len(a[1]),
+            accepted=bool(s.accepted), virtual=bool(s.virtual_layer), reward=float(reward), done=bool(done),
+            services_processed=env.services_processed, services_accepted=env.services_accepted,
+            episode_services_processed=env.episode_services_processed,
+            episode_services_accepted=env.episode_services_accepted,
+            bit_rate_requested=env.bit_rate_requested, bit_rate_provisioned=env.bit_rate_provisioned,
+            number_cuts_total=float(info["number_cuts_total"]), rss_total_metric=float(info["rss_total_metric"]),
+            total_path_length=float(info["total_path_length"]), avrage_gsnr=float(info["avrage_gsnr"]),
+            average_mod_level=float(info["average_mod_level"]), average_path_index=float(info["average_path_index"]),
+            path_index=int(info["path_index"]), physical_paths=int(info["physical_paths"]),
+            episode_service_blocking_rate=float(info["episode_service_blocking_rate"]),
+            bit_rate_blocking_rate=float(info["bit_rate_blocking_rate"]),
+            free_total=int(av.sum()), occ_crc=occ_crc(av), current_time=env.current_time,
+            n_running=len(env.topology.graph["running_services"]),
+        )
+        if done and reset_on_done:
+            env.reset()
+    out = rec.arrays()
+    out["channels"] = np.array(chans, np.int16)
+    out["ch_used"] = np.array(used)
+    out["ch_free"] = np.array(free)
+    out["ch_cap"] = np.array(cap, np.int16)
+    out["final_available_channels"] = np.packbits(
+        env.topology.graph["available_channels"].astype(np.uint8), axis=1, bitorder="little")
+    return out
+
+
+PHY_BASE = dict(seed=10, allow_rejection=True, load=1400, mean_service_holding_time=25, episode_length=200,
+                num_spectrum_resources=64, bit_rate_selection="discrete", number_spectrum_channels=80,
+                number_spectrum_channels_s_band=108, grooming=False)
+
+PHY_CASES = [
+    # tests/test_rmsa_threads_us.py:133-148 (the live configuration: bmfa / bmfa_rss, grooming=False)
+    ("phy_us14_s10_bmfa", "us14_k3", dict(), "bmfa", 800, True),
+    ("phy_us14_s10_bmfa_rss", "us14_k3", dict(), "bmfa_rss", 600, True),
+    ("phy_us14_s11_bmfa_load2400", "us14_k3", dict(seed=11, load=2400), "bmfa", 1500, True),
+    ("phy_jpn12_s3_bmfa", "jpn12_k3", dict(seed=3, load=900), "bmfa", 800, True),
+    ("phy_us14_s12_bmfa_load4000", "us14_k3", dict(seed=12, load=4000), "bmfa", 2600, True),  # reaches blocking
+    # heuristics that always use the virtual (grooming) layer, for the next row of work
+    ("phy_us14_s10_sapff", "us14_k3", dict(), "sapff", 600, True),
+    ("phy_us14_s10_bmff", "us14_k3", dict(), "bmff", 600, True),
+    ("phy_us14_s10_sapbm", "us14_k3", dict(), "sapbm", 600, True),
+]
+
+
+def gen_phy():
+    gen_phy_tables()
+    for name, tab, over, policy, steps, reset in PHY_CASES:
+        kw = dict(PHY_BASE)
+        kw.update(over)
+        topo = load_pickled_topology(TOPOLOGIES[PHY_TABLES[tab][2]])
+        out = run_phy_trace(topo, load_phy_tables(tab), kw, policy, steps, reset)
+        meta = dict(topology=PHY_TABLES[tab][2], tables=tab, env_kwargs=_jsonable(kw), policy=policy, steps=steps,
+                    reset_on_done=reset)
+        out["meta"] = np.array(json.dumps(meta))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "accepted", int(out["services_accepted"][-1]), "/", int(out["services_processed"][-1]),
+              "virtual", int(out["virtual"].sum()), "max channels", int(out["n_channels"].max()),
+              "running", int(out["n_running"].max()), "cuts", out["number_cuts_total"][-1])
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
