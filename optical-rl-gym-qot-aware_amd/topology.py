@@ -175,9 +175,61 @@ class FrozenTopology:
         self.path_link_off = np.asarray(link_off, np.int32)
         self.path_links = np.asarray(links, np.int32)
         self.link_length = np.zeros(E, np.float64)
-        for _, _, idx, _, l in self.edges:
+        self.link_ends = np.zeros((E, 2), np.int32)
+        for a, b, idx, _, l in self.edges:
             self.link_length[idx] = l
+            self.link_ends[idx] = (node_pos[a], node_pos[b])
         self._pair_paths = pair_paths
+        # node ids along every path (CSR), for the neighbour-link "cut" metric of phy_rmsa_env.py:1123-1193
+        node_off, node_ids = [0], []
+        for (a, b), plist in pair_paths.items():
+            for (_, _, _, _, node_list) in plist:
+                node_ids.extend(node_pos[str(n)] for n in node_list)
+                node_off.append(len(node_ids))
+        self.path_node_off = np.asarray(node_off, np.int32)
+        self.path_nodes = np.asarray(node_ids, np.int32)
+
+    def cut_adjacency(self):
+        """Per path: the links adjacent to the path's nodes that are not path links, with weight 1 at the two end
+        nodes and 2 at interior nodes -- ``calculate_r_cut(..., modified=True)`` (``phy_rmsa_env.py:1140-1193``)
+        reduces to  sum_j w_j * (1 - 2 * available[link_j, channel])  for a channel free on the path.
+        Returns CSR arrays (offsets [num_paths+1], links, weights)."""
+        N = self.num_nodes
+        link_of = {}
+        nbrs = [[] for _ in range(N)]
+        for l, (a, b) in enumerate(self.link_ends):
+            link_of[int(a), int(b)] = l
+            link_of[int(b), int(a)] = l
+            nbrs[int(a)].append(int(b))
+            nbrs[int(b)].append(int(a))
+        off, links, weights = [0], [], []
+        for g in range(self.num_paths):
+            nodes = [int(x) for x in self.path_nodes[self.path_node_off[g]:self.path_node_off[g + 1]]]
+            on_path = set(nodes)
+            for i, n in enumerate(nodes):
+                w = 1 if i in (0, len(nodes) - 1) else 2
+                for nk in nbrs[n]:
+                    if nk not in on_path:
+                        links.append(link_of[n, nk])
+                        weights.append(w)
+            off.append(len(links))
+        return np.asarray(off, np.int32), np.asarray(links, np.int32), np.asarray(weights, np.int32)
+
+    def pair_table_rows(self, pairs):
+        """[N*N] row of the QoT tables for every ordered node pair: first row whose (source, destination)
+        node numbers match in either order (``phy_rmsa_env.py:562-565``); -1 where none does."""
+        N = self.num_nodes
+        out = np.full(N * N, -1, np.int32)
+        pairs = np.asarray(pairs)
+        for i, a in enumerate(self.nodes):
+            for j, b in enumerate(self.nodes):
+                if i == j:
+                    continue
+                ia, ib = int(a), int(b)
+                m = np.where(((pairs[:, 0] == ia) & (pairs[:, 1] == ib)) | ((pairs[:, 0] == ib) & (pairs[:, 1] == ia)))[0]
+                if len(m):
+                    out[i * N + j] = m[0]
+        return out
 
     # ------------------------------------------------------------------ constructors
     @classmethod

@@ -266,3 +266,161 @@ def py_random_stream(seed, n):
     out = np.zeros(n)
     lib().orc_py_random_stream(C.c_uint64(seed), n, _ptr(out))
     return out
+
+
+# ----------------------------------------------------------------------------------------- PhyRMSA oracle
+PHY_MAX_CH = 12
+PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1}
+
+
+class PhyConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
+                ("k_table", C.c_int32), ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
+                                          "modulation_level", "gsnr", "link_ends", "path_node_off", "path_nodes")]
+
+
+class PhyAction(C.Structure):
+    _fields_ = [("path", C.c_int32), ("n", C.c_int32), ("ch", C.c_int32 * PHY_MAX_CH), ("cap", C.c_int32 * PHY_MAX_CH),
+                ("used", C.c_double * PHY_MAX_CH), ("free_", C.c_double * PHY_MAX_CH)]
+
+
+class PhyResult(C.Structure):
+    _fields_ = [("reward", C.c_double), ("done", C.c_int32), ("accepted", C.c_int32)] + \
+               [(n, C.c_double) for n in ("number_cuts_total", "rss_total_metric", "total_path_length", "avrage_gsnr",
+                                          "average_path_index", "service_blocking_rate", "episode_service_blocking_rate",
+                                          "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")] + \
+               [(n, C.c_int64) for n in ("total_modulation_level", "channels_accepted", "path_index", "physical_paths")]
+
+
+PHY_TRACE_FIELDS = [
+    ("service_id", np.int32, 1), ("src", np.int32, 1), ("dst", np.int32, 1), ("bit_rate", np.int32, 1),
+    ("act_path", np.int32, 1), ("n_channels", np.int32, 1), ("channels", np.int32, PHY_MAX_CH),
+    ("arrival", np.float64, 1), ("holding", np.float64, 1), ("ch_used", np.float64, PHY_MAX_CH),
+    ("accepted", np.uint8, 1), ("done", np.uint8, 1),
+    ("services_accepted", np.int64, 1), ("total_modulation_level", np.int64, 1), ("channels_accepted", np.int64, 1),
+    ("path_index", np.int64, 1), ("physical_paths", np.int64, 1), ("n_running", np.int64, 1), ("free_total", np.int64, 1),
+    ("number_cuts_total", np.float64, 1), ("rss_total_metric", np.float64, 1), ("total_path_length", np.float64, 1),
+    ("avrage_gsnr", np.float64, 1), ("average_path_index", np.float64, 1),
+    ("episode_service_blocking_rate", np.float64, 1), ("bit_rate_blocking_rate", np.float64, 1),
+    ("current_time", np.float64, 1),
+]
+
+
+class PhyTrace(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _, _ in PHY_TRACE_FIELDS]
+
+
+def _phy_lib(asan=False):
+    L = lib(asan)
+    if not getattr(L, "_phy_ready", False):
+        L.orc_phy_create.restype = C.c_void_p
+        L.orc_phy_create.argtypes = [C.POINTER(Topology), C.POINTER(PhyConfig), C.c_uint64]
+        L.orc_phy_destroy.argtypes = [C.c_void_p]
+        L.orc_phy_reset.argtypes = [C.c_void_p, C.c_int]
+        L.orc_phy_get_request.argtypes = [C.c_void_p, C.POINTER(Request)]
+        L.orc_phy_policy.argtypes = [C.c_void_p, C.c_int, C.POINTER(PhyAction)]
+        L.orc_phy_step.argtypes = [C.c_void_p, C.POINTER(PhyAction), C.POINTER(PhyResult)]
+        L.orc_phy_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.orc_phy_current_time.restype = C.c_double
+        L.orc_phy_current_time.argtypes = [C.c_void_p]
+        L.orc_phy_get_available_channels.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_phy_num_running.argtypes = [C.c_void_p]
+        L.orc_phy_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(PhyTrace)]
+        L._phy_ready = True
+    return L
+
+
+class PhyOracleEnv:
+    """One reference-semantics PhyRMSAEnv (physical layer, grooming off) on the CPU."""
+
+    def __init__(self, tables, *, num_channels, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
+                 arrival_lambda, holding_lambda, pair_table_row, modulation_level, gsnr, link_ends, path_node_off,
+                 path_nodes, seed=41, asan=False):
+        self.L = _phy_lib(asan)
+        self._keep = []
+
+        def keep(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            self._keep.append(a)
+            return _ptr(a)
+
+        t = Topology()
+        t.num_nodes, t.num_links, t.k_paths = int(tables["num_nodes"]), int(tables["num_links"]), int(tables["k_paths"])
+        t.num_paths = len(tables["path_hops"])
+        for name, dt in (("pair_path_base", np.int32), ("pair_path_count", np.int32), ("path_hops", np.int32),
+                         ("path_se", np.int32), ("path_length", np.float64), ("path_link_off", np.int32),
+                         ("path_links", np.int32)):
+            setattr(t, name, keep(tables[name], dt))
+        c = PhyConfig()
+        c.num_channels, c.episode_length, c.num_bit_rates = int(num_channels), int(episode_length), len(bit_rates)
+        c.k_table = int(np.asarray(modulation_level).shape[2])
+        c.arrival_lambda, c.holding_lambda = float(arrival_lambda), float(holding_lambda)
+        c.bit_rates = keep(bit_rates, np.int32)
+        c.bit_rate_cum = keep(bit_rate_cum, np.float64)
+        c.src_cum = keep(src_cum, np.float64)
+        c.dst_cum = keep(dst_cum, np.float64)
+        c.pair_table_row = keep(pair_table_row, np.int32)
+        c.modulation_level = keep(modulation_level, np.uint8)
+        c.gsnr = keep(gsnr, np.float64)
+        c.link_ends = keep(link_ends, np.int32)
+        c.path_node_off = keep(path_node_off, np.int32)
+        c.path_nodes = keep(path_nodes, np.int32)
+        self.E, self.Cn = t.num_links, int(num_channels)
+        self._t, self._c = t, c
+        self.h = self.L.orc_phy_create(C.byref(t), C.byref(c), C.c_uint64(int(seed)))
+
+    def close(self):
+        if self.h:
+            self.L.orc_phy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, only_episode_counters=True):
+        self.L.orc_phy_reset(self.h, 1 if only_episode_counters else 0)
+
+    def request(self):
+        r = Request()
+        self.L.orc_phy_get_request(self.h, C.byref(r))
+        return r
+
+    def policy(self, name):
+        a = PhyAction()
+        self.L.orc_phy_policy(self.h, PHY_POLICY[name], C.byref(a))
+        return a
+
+    def step(self, action):
+        r = PhyResult()
+        self.L.orc_phy_step(self.h, C.byref(action), C.byref(r))
+        return r
+
+    def counters(self):
+        c = Counters()
+        self.L.orc_phy_get_counters(self.h, C.byref(c))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def current_time(self):
+        return self.L.orc_phy_current_time(self.h)
+
+    def available_channels(self):
+        a = np.zeros((self.E, self.Cn), np.uint8)
+        self.L.orc_phy_get_available_channels(self.h, _ptr(a))
+        return a
+
+    def num_running(self):
+        return self.L.orc_phy_num_running(self.h)
+
+    def run(self, policy, n_steps, reset_on_done=False, fields=None):
+        tr = PhyTrace()
+        out = {}
+        for name, dt, width in PHY_TRACE_FIELDS:
+            if fields is None or name in fields:
+                out[name] = np.zeros((n_steps, width) if width > 1 else n_steps, dt)
+                setattr(tr, name, _ptr(out[name]))
+        self.L.orc_phy_run(self.h, PHY_POLICY[policy], int(n_steps), 1 if reset_on_done else 0, C.byref(tr))
+        return out

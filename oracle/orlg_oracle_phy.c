@@ -1,0 +1,460 @@
+/*
+ * oracle/orlg_oracle_phy.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see orlg_oracle.h).
+ *
+ * CPU restatement of the QoT-aware environment's core, optical_rl_gym/envs/phy_rmsa_env.py (PhyRMSAEnv),
+ * in the reference's own representation (one byte per (link, channel), run-length encoding along the
+ * link axis for the cut / RSS fragmentation metrics, a binary heap of release events).  Scope: the
+ * physical layer as the reference's live experiment configuration runs it
+ * (tests/test_rmsa_threads_us.py:133-148: grooming=False, heuristics phy_aware_bmfa_rmsa /
+ * phy_aware_bmfa_rss_rmsa).  With grooming off the residual-capacity lists (channel_state) are written but
+ * never read, and every channel of a service is returned on release (phy_rmsa_env.py:781-861 with
+ * result[1] == channel[1] always true), so they are not kept here.  The virtual (grooming) layer and the
+ * periodic defragmentation (phy_rmsa_env.py:355-417, 625-764) are NOT restated yet.
+ *
+ * Pinned bit for bit (floats included) against tests/golden/phy_*_bmfa*.npz recorded from the reference.
+ */
+#include "orlg_oracle_phy.h"
+
+#include "orlg_oracle_common.h"
+
+typedef struct pservice {
+    int32_t service_id, src, dst, bit_rate, br_index;
+    double arrival_time, holding_time;
+    int32_t path_gid, idp, nch;
+    int32_t ch[ORC_PHY_MAX_CH];
+    int32_t accepted;
+    int64_t seq;
+} pservice;
+
+typedef struct { double time; pservice *svc; } pevent;
+
+struct orc_phy_env {
+    orc_topology topo;
+    orc_phy_config cfg;
+    int N, E, C, K;
+    py_rng rng;
+    uint8_t *avail;     /* topology.graph["available_channels"], E*C, 1 = free */
+    int *link_of;       /* [N*N] link index of edge (a,b), -1 if none */
+    double current_time;
+    orc_counters c;
+    /* per-episode statistics of phy_rmsa_env.py:101-112 */
+    double total_path_length_episode, total_gsnr_episode;
+    int64_t total_path_index_episode, total_modulation_level_episode, channels_accepted_episode,
+        physical_services_accepted_episode;
+    pservice *current;
+    int new_service;
+    pservice **running;
+    int n_running, cap_running;
+    pevent *heap;
+    int n_heap, cap_heap;
+    int64_t seq;
+    uint8_t *col, *col2;
+    int *r_start, *r_len;
+    uint8_t *r_val;
+};
+
+static int ppath_gid(const orc_phy_env *e, int s, int d, int idp) { return e->topo.pair_path_base[s * e->N + d] + idp; }
+
+static int prle(const uint8_t *a, int n, int *starts, uint8_t *values, int *lengths) {
+    if (n == 0) return 0;
+    int runs = 0, s = 0;
+    for (int i = 1; i <= n; i++)
+        if (i == n || a[i] != a[i - 1]) { starts[runs] = s; values[runs] = a[s]; lengths[runs] = i - s; runs++; s = i; }
+    return runs;
+}
+
+static void column(const orc_phy_env *e, int ch, uint8_t *out) {
+    for (int l = 0; l < e->E; l++) out[l] = e->avail[(size_t)l * e->C + ch];
+}
+
+/* phy_rmsa_env.py:1029-1035 */
+static int is_channel_free(const orc_phy_env *e, int gid, int ch) {
+    for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+        if (e->avail[(size_t)e->topo.path_links[h] * e->C + ch] == 0) return 0;
+    return 1;
+}
+
+/* phy_rmsa_env.py:1123-1193, modified=True, defrag_flag=False: cuts against the links adjacent to the
+ * path's nodes before minus after taking the channel on the path's links */
+static int r_cut_modified(orc_phy_env *e, int gid, int ch) {
+    const int32_t *nodes = e->cfg.path_nodes + e->cfg.path_node_off[gid];
+    int nn = e->cfg.path_node_off[gid + 1] - e->cfg.path_node_off[gid];
+    int before = 0, after = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        column(e, ch, e->col);
+        if (pass == 1)
+            for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++) e->col[e->topo.path_links[h]] = 0;
+        int acc = 0;
+        for (int i = 0; i < nn; i++) {
+            for (int nk = 0; nk < e->N; nk++) {
+                int l = e->link_of[nodes[i] * e->N + nk];
+                if (l < 0) continue;
+                int on_path = 0;
+                for (int q = 0; q < nn; q++) on_path |= (nodes[q] == nk);
+                if (on_path) continue;
+                if (i == nn - 1) {
+                    acc += abs((int)e->col[e->link_of[nodes[i - 1] * e->N + nodes[i]]] - (int)e->col[l]);
+                } else if (i == 0) {
+                    acc += abs((int)e->col[e->link_of[nodes[0] * e->N + nodes[1]]] - (int)e->col[l]);
+                } else {
+                    acc += abs((int)e->col[e->link_of[nodes[i] * e->N + nodes[i + 1]]] - (int)e->col[l]) +
+                           abs((int)e->col[e->link_of[nodes[i - 1] * e->N + nodes[i]]] - (int)e->col[l]);
+                }
+            }
+        }
+        if (pass == 0) before = acc; else after = acc;
+    }
+    return before - after;
+}
+
+static double rss_of_column(orc_phy_env *e, const uint8_t *col) {
+    int runs = prle(col, e->E, e->r_start, e->r_val, e->r_len);
+    int64_t sq = 0, sm = 0;
+    for (int i = 0; i < runs; i++)
+        if (e->r_val[i] == 1) { sq += (int64_t)e->r_len[i] * e->r_len[i]; sm += e->r_len[i]; }
+    return sqrt((double)sq) / (double)(sm + 1);
+}
+
+/* phy_rmsa_env.py:1085-1108, defrag_flag=False */
+static double r_spatial(orc_phy_env *e, int gid, int ch) {
+    column(e, ch, e->col);
+    double r0 = 0 + rss_of_column(e, e->col);
+    memcpy(e->col2, e->col, e->E);
+    for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++) e->col2[e->topo.path_links[h]] = 0;
+    double r1 = 0 + rss_of_column(e, e->col2);
+    return r1 - r0;
+}
+
+/* phy_rmsa_env.py:1195-1203 */
+static double total_cuts(orc_phy_env *e) {
+    int64_t n = 0;
+    for (int ch = 0; ch < e->C; ch++) {
+        column(e, ch, e->col);
+        int runs = prle(e->col, e->E, e->r_start, e->r_val, e->r_len);
+        for (int i = 0; i < runs; i++) n += e->r_val[i];
+    }
+    return (double)n / (double)e->C;
+}
+
+/* phy_rmsa_env.py:1110-1121 */
+static double total_r_spatial(orc_phy_env *e) {
+    double r = 0;
+    for (int ch = 0; ch < e->C; ch++) {
+        column(e, ch, e->col);
+        r += rss_of_column(e, e->col);
+    }
+    return r / (double)e->C;
+}
+
+/* heap */
+static int pev_less(const pevent *a, const pevent *b) {
+    if (a->time != b->time) return a->time < b->time;
+    return a->svc->seq < b->svc->seq;
+}
+static void pheap_push(orc_phy_env *e, double t, pservice *s) {
+    if (e->n_heap == e->cap_heap) {
+        e->cap_heap = e->cap_heap ? 2 * e->cap_heap : 1024;
+        e->heap = (pevent *)realloc(e->heap, sizeof(pevent) * e->cap_heap);
+    }
+    int i = e->n_heap++;
+    e->heap[i].time = t; e->heap[i].svc = s;
+    while (i > 0) {
+        int p = (i - 1) / 2;
+        if (!pev_less(&e->heap[i], &e->heap[p])) break;
+        pevent tmp = e->heap[i]; e->heap[i] = e->heap[p]; e->heap[p] = tmp;
+        i = p;
+    }
+}
+static pevent pheap_pop(orc_phy_env *e) {
+    pevent top = e->heap[0];
+    e->heap[0] = e->heap[--e->n_heap];
+    int i = 0;
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, m = i;
+        if (l < e->n_heap && pev_less(&e->heap[l], &e->heap[m])) m = l;
+        if (r < e->n_heap && pev_less(&e->heap[r], &e->heap[m])) m = r;
+        if (m == i) break;
+        pevent tmp = e->heap[i]; e->heap[i] = e->heap[m]; e->heap[m] = tmp;
+        i = m;
+    }
+    return top;
+}
+
+/* phy_rmsa_env.py:781-861 with grooming off: every channel of the service is returned */
+static void release_path(orc_phy_env *e, pservice *s) {
+    for (int h = e->topo.path_link_off[s->path_gid]; h < e->topo.path_link_off[s->path_gid + 1]; h++)
+        for (int i = 0; i < s->nch; i++) e->avail[(size_t)e->topo.path_links[h] * e->C + s->ch[i]] = 1;
+    for (int i = 0; i < e->n_running; i++)
+        if (e->running[i] == s) {
+            memmove(&e->running[i], &e->running[i + 1], sizeof(pservice *) * (e->n_running - i - 1));
+            e->n_running--;
+            break;
+        }
+}
+
+/* phy_rmsa_env.py:969-1017 */
+static void next_service(orc_phy_env *e) {
+    if (e->new_service) return;
+    double at = e->current_time + py_expovariate(&e->rng, e->cfg.arrival_lambda);
+    e->current_time = at;
+    double ht = py_expovariate(&e->rng, e->cfg.holding_lambda);
+    int src = py_choice_cum(&e->rng, e->cfg.src_cum, e->N);
+    int dst = py_choice_cum(&e->rng, e->cfg.dst_cum + (size_t)src * e->N, e->N);
+    int bri = py_choice_cum(&e->rng, e->cfg.bit_rate_cum, e->cfg.num_bit_rates);
+    pservice *s = (pservice *)calloc(1, sizeof(pservice));
+    s->service_id = (int32_t)e->c.episode_services_processed;
+    s->src = src; s->dst = dst; s->br_index = bri; s->bit_rate = e->cfg.bit_rates[bri];
+    s->arrival_time = at; s->holding_time = ht; s->seq = e->seq++;
+    if (e->current && !e->current->accepted) free(e->current);
+    e->current = s;
+    e->new_service = 1;
+    e->c.services_processed++; e->c.episode_services_processed++;
+    e->c.bit_rate_requested += s->bit_rate; e->c.episode_bit_rate_requested += s->bit_rate;
+    while (e->n_heap > 0) {
+        pevent ev = pheap_pop(e);
+        if (ev.time <= e->current_time) {
+            release_path(e, ev.svc);
+            free(ev.svc);
+        } else {
+            pheap_push(e, ev.time, ev.svc);
+            break;
+        }
+    }
+}
+
+/* phy_rmsa_env.py:426-539 */
+void orc_phy_reset(orc_phy_env *e, int only_episode_counters) {
+    e->c.episode_bit_rate_requested = 0; e->c.episode_bit_rate_provisioned = 0;
+    e->c.episode_services_processed = 0; e->c.episode_services_accepted = 0;
+    e->total_path_length_episode = 0; e->total_path_index_episode = 0; e->total_gsnr_episode = 0;
+    e->total_modulation_level_episode = 0; e->channels_accepted_episode = 0;
+    e->physical_services_accepted_episode = 0;
+    if (only_episode_counters) {
+        if (e->new_service) {
+            e->c.episode_services_processed += 1;
+            e->c.episode_bit_rate_requested += e->current->bit_rate;
+        }
+        return;
+    }
+    for (int i = 0; i < e->n_heap; i++) free(e->heap[i].svc);
+    e->n_heap = 0; e->n_running = 0;
+    if (e->current && !e->current->accepted) free(e->current);
+    e->current = NULL;
+    e->current_time = 0;
+    memset(&e->c, 0, sizeof(e->c));
+    memset(e->avail, 1, (size_t)e->E * e->C);
+    e->new_service = 0;
+    next_service(e);
+}
+
+orc_phy_env *orc_phy_create(const orc_topology *topo, const orc_phy_config *cfg, uint64_t seed) {
+    orc_phy_env *e = (orc_phy_env *)calloc(1, sizeof(orc_phy_env));
+    e->topo = *topo; e->cfg = *cfg;
+    e->N = topo->num_nodes; e->E = topo->num_links; e->C = cfg->num_channels; e->K = topo->k_paths;
+    py_seed(&e->rng, seed);
+    e->avail = (uint8_t *)malloc((size_t)e->E * e->C);
+    e->link_of = (int *)malloc(sizeof(int) * e->N * e->N);
+    for (int i = 0; i < e->N * e->N; i++) e->link_of[i] = -1;
+    for (int l = 0; l < e->E; l++) {
+        int a = cfg->link_ends[2 * l], b = cfg->link_ends[2 * l + 1];
+        e->link_of[a * e->N + b] = l;
+        e->link_of[b * e->N + a] = l;
+    }
+    e->col = (uint8_t *)malloc(e->E); e->col2 = (uint8_t *)malloc(e->E);
+    e->r_start = (int *)malloc(sizeof(int) * (e->E + 1));
+    e->r_len = (int *)malloc(sizeof(int) * (e->E + 1));
+    e->r_val = (uint8_t *)malloc(e->E + 1);
+    orc_phy_reset(e, 0);
+    return e;
+}
+
+void orc_phy_destroy(orc_phy_env *e) {
+    if (!e) return;
+    for (int i = 0; i < e->n_heap; i++) free(e->heap[i].svc);
+    if (e->current && !e->current->accepted) free(e->current);
+    free(e->heap); free(e->running); free(e->avail); free(e->link_of); free(e->col); free(e->col2);
+    free(e->r_start); free(e->r_len); free(e->r_val);
+    free(e);
+}
+
+void orc_phy_get_request(const orc_phy_env *e, orc_request *o) {
+    o->service_id = e->current->service_id; o->src = e->current->src; o->dst = e->current->dst;
+    o->bit_rate = e->current->bit_rate; o->arrival_time = e->current->arrival_time;
+    o->holding_time = e->current->holding_time;
+}
+
+/* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438, metric = calculate_r_cut modified) and
+ * phy_aware_bmfa_rss_rmsa (:1441-1505, metric = calculate_r_spatial), grooming off */
+typedef struct { int mod; double frag; int ch, idp, pos; uint8_t key0; } cand;
+static int cand_cmp(const void *a, const void *b) {
+    const cand *x = (const cand *)a, *y = (const cand *)b;
+    /* key (-x[0], -x[1]): -np.uint8 wraps (key0), -frag ascending = frag descending; stable */
+    if (x->key0 != y->key0) return x->key0 < y->key0 ? -1 : 1;
+    if (x->frag != y->frag) return x->frag > y->frag ? -1 : 1;
+    return x->pos - y->pos;
+}
+
+void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
+    const pservice *s = e->current;
+    int K = e->K, C = e->C;
+    int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
+    cand *rows = (cand *)malloc(sizeof(cand) * (size_t)K * C);
+    int *cnt = (int *)calloc(K, sizeof(int));
+    int *alive = (int *)malloc(sizeof(int) * K);
+    for (int idp = 0; idp < K; idp++) {
+        int gid = ppath_gid(e, s->src, s->dst, idp);
+        alive[idp] = 1;
+        for (int ch = 0; ch < C; ch++)
+            if (is_channel_free(e, gid, ch)) {
+                cand *c = &rows[(size_t)idp * C + cnt[idp]];
+                c->mod = e->cfg.modulation_level[((size_t)row * C + ch) * e->cfg.k_table + idp];
+                c->frag = policy == ORC_PHY_POLICY_BMFA_RSS ? r_spatial(e, gid, ch) : (double)r_cut_modified(e, gid, ch);
+                c->ch = ch; c->idp = idp; c->pos = cnt[idp]; c->key0 = (uint8_t)(-c->mod);
+                cnt[idp]++;
+            }
+        qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cand_cmp);
+    }
+    act->path = -2; act->n = 0;
+    for (;;) {
+        double max_mod = -INFINITY, max_frag = -INFINITY;
+        int best = -1;
+        for (int i = 0; i < K; i++) {
+            if (!alive[i] || cnt[i] == 0) continue;
+            const cand *h = &rows[(size_t)i * C];
+            if ((double)h->mod > max_mod || ((double)h->mod == max_mod && h->frag > max_frag)) {
+                max_mod = h->mod; max_frag = h->frag; best = i;
+            }
+        }
+        if (best < 0) break;
+        double unassigned = s->bit_rate;
+        int n = 0, covered = 0;
+        for (int q = 0; q < cnt[best] && n < ORC_PHY_MAX_CH; q++) {
+            const cand *c = &rows[(size_t)best * C + q];
+            unassigned -= c->mod * 100;
+            act->ch[n] = c->ch; act->cap[n] = c->mod;
+            if (unassigned <= 0) {
+                act->used[n] = c->mod + unassigned / 100; act->free_[n] = unassigned / -100;
+                n++; covered = 1;
+                break;
+            }
+            act->used[n] = c->mod; act->free_[n] = 0;
+            n++;
+        }
+        if (covered) { act->path = best; act->n = n; break; }
+        alive[best] = 0;
+    }
+    free(rows); free(cnt); free(alive);
+}
+
+/* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424), physical layer */
+void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out) {
+    pservice *s = e->current;
+    s->accepted = 0;
+    if (act->path != -2 && act->path >= 0 && act->path < e->K) {
+        int gid = ppath_gid(e, s->src, s->dst, act->path);
+        int free_flag = 1; /* is_path_free_on_channels :1019-1027 */
+        for (int i = 0; i < act->n; i++) free_flag &= is_channel_free(e, gid, act->ch[i]);
+        if (free_flag) {
+            /* _provision_path :544-623 */
+            int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
+            for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+                for (int i = 0; i < act->n; i++) e->avail[(size_t)e->topo.path_links[h] * e->C + act->ch[i]] = 0;
+            for (int i = 0; i < act->n; i++) {
+                double g = e->cfg.gsnr[((size_t)row * e->C + act->ch[i]) * e->cfg.k_table + act->path];
+                e->total_gsnr_episode += g;
+                e->total_modulation_level_episode += act->cap[i];
+                e->channels_accepted_episode += 1;
+                s->ch[i] = act->ch[i];
+            }
+            s->nch = act->n; s->path_gid = gid; s->idp = act->path;
+            if (e->n_running == e->cap_running) {
+                e->cap_running = e->cap_running ? 2 * e->cap_running : 1024;
+                e->running = (pservice **)realloc(e->running, sizeof(pservice *) * e->cap_running);
+            }
+            e->running[e->n_running++] = s;
+            /* _service_acceptance(False) :767-778 */
+            s->accepted = 1;
+            e->c.services_accepted++; e->c.episode_services_accepted++;
+            e->total_path_length_episode += e->topo.path_length[gid];
+            e->total_path_index_episode += act->path + 1;
+            e->physical_services_accepted_episode += 1;
+            e->c.bit_rate_provisioned += s->bit_rate; e->c.episode_bit_rate_provisioned += s->bit_rate;
+            pheap_push(e, s->arrival_time + s->holding_time, s);
+        }
+    }
+    if (out) {
+        out->accepted = s->accepted;
+        out->reward = s->accepted ? 1.0 : 0.0;
+        out->number_cuts_total = total_cuts(e);
+        out->rss_total_metric = total_r_spatial(e);
+        out->service_blocking_rate = (double)(e->c.services_processed - e->c.services_accepted) / (double)e->c.services_processed;
+        out->episode_service_blocking_rate = (double)(e->c.episode_services_processed - e->c.episode_services_accepted) /
+                                             (double)e->c.episode_services_processed;
+        out->bit_rate_blocking_rate = (double)(e->c.bit_rate_requested - e->c.bit_rate_provisioned) / (double)e->c.bit_rate_requested;
+        out->episode_bit_rate_blocking_rate = (double)(e->c.episode_bit_rate_requested - e->c.episode_bit_rate_provisioned) /
+                                              (double)e->c.episode_bit_rate_requested;
+        out->total_path_length = e->total_path_length_episode / (double)(e->physical_services_accepted_episode + 1);
+        out->avrage_gsnr = e->total_gsnr_episode / (double)(e->channels_accepted_episode + 1);
+        out->total_modulation_level = e->total_modulation_level_episode;
+        out->channels_accepted = e->channels_accepted_episode;
+        out->average_path_index = (double)e->total_path_index_episode / (double)(e->physical_services_accepted_episode + 1);
+        out->path_index = e->total_path_index_episode;
+        out->physical_paths = e->physical_services_accepted_episode;
+    }
+    e->new_service = 0;
+    next_service(e);
+    if (out) out->done = (e->c.episode_services_processed == e->cfg.episode_length);
+}
+
+void orc_phy_get_counters(const orc_phy_env *e, orc_counters *out) { *out = e->c; }
+double orc_phy_current_time(const orc_phy_env *e) { return e->current_time; }
+void orc_phy_get_available_channels(const orc_phy_env *e, uint8_t *out) { memcpy(out, e->avail, (size_t)e->E * e->C); }
+int orc_phy_num_running(const orc_phy_env *e) { return e->n_running; }
+
+void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done, orc_phy_trace *tr) {
+    orc_phy_action act;
+    orc_phy_result r;
+    for (int64_t i = 0; i < n_steps; i++) {
+        const pservice *s = e->current;
+        if (tr) {
+            if (tr->service_id) tr->service_id[i] = s->service_id;
+            if (tr->src) tr->src[i] = s->src;
+            if (tr->dst) tr->dst[i] = s->dst;
+            if (tr->bit_rate) tr->bit_rate[i] = s->bit_rate;
+            if (tr->arrival) tr->arrival[i] = s->arrival_time;
+            if (tr->holding) tr->holding[i] = s->holding_time;
+        }
+        orc_phy_policy(e, policy, &act);
+        orc_phy_step(e, &act, &r);
+        if (tr) {
+            if (tr->act_path) tr->act_path[i] = act.path;
+            if (tr->n_channels) tr->n_channels[i] = act.n;
+            if (tr->channels)
+                for (int q = 0; q < ORC_PHY_MAX_CH; q++) tr->channels[i * ORC_PHY_MAX_CH + q] = q < act.n ? act.ch[q] : -1;
+            if (tr->ch_used)
+                for (int q = 0; q < ORC_PHY_MAX_CH; q++) tr->ch_used[i * ORC_PHY_MAX_CH + q] = q < act.n ? act.used[q] : 0.0;
+            if (tr->accepted) tr->accepted[i] = (uint8_t)r.accepted;
+            if (tr->done) tr->done[i] = (uint8_t)r.done;
+            if (tr->services_accepted) tr->services_accepted[i] = e->c.services_accepted;
+            if (tr->number_cuts_total) tr->number_cuts_total[i] = r.number_cuts_total;
+            if (tr->rss_total_metric) tr->rss_total_metric[i] = r.rss_total_metric;
+            if (tr->total_path_length) tr->total_path_length[i] = r.total_path_length;
+            if (tr->avrage_gsnr) tr->avrage_gsnr[i] = r.avrage_gsnr;
+            if (tr->total_modulation_level) tr->total_modulation_level[i] = r.total_modulation_level;
+            if (tr->channels_accepted) tr->channels_accepted[i] = r.channels_accepted;
+            if (tr->average_path_index) tr->average_path_index[i] = r.average_path_index;
+            if (tr->path_index) tr->path_index[i] = r.path_index;
+            if (tr->physical_paths) tr->physical_paths[i] = r.physical_paths;
+            if (tr->episode_service_blocking_rate) tr->episode_service_blocking_rate[i] = r.episode_service_blocking_rate;
+            if (tr->bit_rate_blocking_rate) tr->bit_rate_blocking_rate[i] = r.bit_rate_blocking_rate;
+            if (tr->current_time) tr->current_time[i] = e->current_time;
+            if (tr->n_running) tr->n_running[i] = e->n_running;
+            if (tr->free_total) {
+                int64_t f = 0;
+                for (size_t q = 0; q < (size_t)e->E * e->C; q++) f += e->avail[q];
+                tr->free_total[i] = f;
+            }
+        }
+        if (r.done && reset_on_done) orc_phy_reset(e, 1);
+    }
+}

@@ -73,3 +73,31 @@ def deeprmsa_to_rmsa_kwargs(kw):
                episode_length=kw.get("episode_length", 1000), seed=kw.get("seed"),
                node_request_probabilities=kw.get("node_request_probabilities"))
     return out, j
+
+
+PHY_DEFAULT_BIT_RATES = [100, 200, 300, 400, 500, 600]  # phy_rmsa_env.py:38
+
+
+def load_phy_tables(name):
+    z = np.load(os.path.join(GOLDEN, "tables", name + ".npz"), allow_pickle=False)
+    return z["pairs"], z["modulation_level"], z["gsnr"]
+
+
+def phy_oracle_from_kwargs(topo, tables, env_kwargs, seed=None, asan=False):
+    """Oracle PhyRMSAEnv from reference-style kwargs (phy_rmsa_env.py:30-58), physical layer only."""
+    import oracle as orc
+    from optical_rl_gym_amd import selection_tables
+    kw = dict(env_kwargs)
+    pairs, mod, gsnr = tables
+    bit_rates = kw.get("bit_rates", PHY_DEFAULT_BIT_RATES)
+    _, src_cum, dst_cum, br_cum = selection_tables(kw.get("node_request_probabilities"),
+                                                   kw.get("bit_rate_probabilities"), topo.num_nodes, bit_rates)
+    load, ht = kw.get("load", 10), kw.get("mean_service_holding_time", 10800.0)
+    mean_iat = 1 / float(load / float(ht))
+    nch = 2 * kw.get("number_spectrum_channels", 80) + kw.get("number_spectrum_channels_s_band", 108)
+    return orc.PhyOracleEnv(topology_tables(topo), num_channels=nch, episode_length=kw.get("episode_length", 1000),
+                            bit_rates=bit_rates, bit_rate_cum=br_cum, src_cum=src_cum, dst_cum=dst_cum,
+                            arrival_lambda=1 / mean_iat, holding_lambda=1 / ht,
+                            pair_table_row=topo.pair_table_rows(pairs), modulation_level=mod, gsnr=gsnr,
+                            link_ends=topo.link_ends, path_node_off=topo.path_node_off, path_nodes=topo.path_nodes,
+                            seed=kw.get("seed", 41) if seed is None else seed, asan=asan)

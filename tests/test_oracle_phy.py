@@ -1,0 +1,38 @@
+"""Oracle PhyRMSAEnv (physical layer, grooming off) against golden traces of the reference: bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, load_phy_tables, load_topology, phy_oracle_from_kwargs
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "phy_*_bmfa*.npz")))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_phy_trace_bit_exact(case):
+    z, meta = load_golden(case)
+    topo = load_topology(meta["topology"])
+    env = phy_oracle_from_kwargs(topo, load_phy_tables(meta["tables"]), meta["env_kwargs"])
+    n = meta["steps"]
+    tr = env.run(meta["policy"], n, reset_on_done=meta["reset_on_done"])
+    assert np.array_equal(tr["src"], z["src_id"]) and np.array_equal(tr["dst"], z["dst_id"])
+    assert np.array_equal(tr["bit_rate"], z["bit_rate"]) and np.array_equal(tr["service_id"], z["service_id"])
+    assert np.array_equal(tr["arrival"], z["arrival"]) and np.array_equal(tr["holding"], z["holding"])
+    assert np.array_equal(tr["act_path"], z["act_path"])
+    assert np.array_equal(tr["n_channels"], z["n_channels"])
+    assert np.array_equal(tr["channels"], z["channels"].astype(np.int32))
+    assert np.array_equal(tr["ch_used"], z["ch_used"])
+    for f in ("accepted", "done", "services_accepted", "path_index", "physical_paths", "n_running", "free_total"):
+        assert np.array_equal(tr[f].astype(np.int64), z[f].astype(np.int64)), f
+    for f in ("number_cuts_total", "rss_total_metric", "total_path_length", "avrage_gsnr", "average_path_index",
+              "episode_service_blocking_rate", "bit_rate_blocking_rate", "current_time"):
+        bad = np.nonzero(tr[f] != z[f])[0]
+        assert bad.size == 0, (f, bad[:5], tr[f][bad[:5]], z[f][bad[:5]])
+    # average_mod_level: under NumPy >= 2 the reference's accumulator is a uint8 that wraps
+    # (phy_rmsa_env.py:598, SURVEY 8c caveat 2); the oracle keeps the true integer total
+    want = (tr["total_modulation_level"] % 256) / (tr["channels_accepted"] + 1)
+    assert np.array_equal(want, z["average_mod_level"])
+    av = env.available_channels()
+    assert np.array_equal(np.packbits(av, axis=1, bitorder="little"), z["final_available_channels"])
