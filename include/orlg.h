@@ -176,6 +176,76 @@ int orlg_deeprmsa_obs_dim(orlg_env *env);
  * out[8] = total episodes done, out[9] = B.  The caller all-reduces this vector (RCCL, SUM). */
 int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */);
 
+/* ------------------------------------------------------------------------------------------------
+ * QoT-aware environment, physical layer: PhyRMSAEnv (optical_rl_gym/envs/phy_rmsa_env.py) as the reference's live
+ * experiment configuration runs it (tests/test_rmsa_threads_us.py:133-148: grooming=False, no periodic
+ * defragmentation).  Allocation is per CHANNEL (L+C+S bands = 268 channels, non-contiguous); the QoT gate is the
+ * table modulation_level[pair row][channel][k-path] (capacity = level x 100 Gb/s); GSNR[...] feeds the statistics.
+ */
+typedef struct orlg_phy_config {
+    int32_t num_channels;     /* 2*number_spectrum_channels + number_spectrum_channels_s_band (optical_network_env.py:78-84) */
+    int32_t episode_length;
+    int32_t num_bit_rates;
+    int32_t k_table;          /* k-path columns of the tables (>= topology k_paths) */
+    int32_t num_table_rows;
+    int32_t queue_capacity;   /* running services per env, multiple of 64; 0 = from the load */
+    double arrival_lambda, holding_lambda;
+    const int32_t *bit_rates;           /* [num_bit_rates], default 100..600 (phy_rmsa_env.py:38) */
+    const double *bit_rate_cum, *src_cum, *dst_cum;
+    const int32_t *pair_table_row;      /* [N*N] table row of (src, dst) in either order (phy_rmsa_env.py:562-565) */
+    const uint8_t *modulation_level;    /* [rows][channels][k_table], every used entry >= 1 */
+    const double *gsnr;                 /* [rows][channels][k_table] */
+    /* calculate_r_cut(modified=True) (phy_rmsa_env.py:1140-1193): per path the links adjacent to its nodes that are
+     * not on the path, weight 1 at the end nodes and 2 at interior nodes (CSR over path records) */
+    const int32_t *adj_off, *adj_link, *adj_weight;
+} orlg_phy_config;
+
+enum {
+    ORLG_PHY_POLICY_EXTERNAL = -1, /* caller supplies (path, channels) per env */
+    ORLG_PHY_POLICY_BMFA_CUT = 0,  /* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438), grooming off */
+};
+#define ORLG_PHY_MAX_CHANNELS 14 /* channels per service */
+
+typedef struct orlg_phy_step_io { /* optional per-step outputs, [n_steps][B] each */
+    int32_t *act_path;          /* -2 = blocked */
+    int32_t *n_channels;
+    int16_t *channels;          /* [n_steps][B][ORLG_PHY_MAX_CHANNELS], -1 padded, in allocation order */
+    uint8_t *accepted, *done;
+    int32_t *request;           /* [n_steps][B][4] service_id, source_id, destination_id, bit_rate */
+    double *arrival, *holding;
+    double *number_cuts_total;  /* info["number_cuts_total"] (_calculate_total_cuts, phy_rmsa_env.py:1195-1203) */
+    double *rss_total_metric;   /* info["rss_total_metric"] (calculate_total_r_spatial, :1110-1121) */
+} orlg_phy_step_io;
+
+typedef struct orlg_phy_episode_stats { /* per-episode sums behind the info dict (phy_rmsa_env.py:339-347) */
+    double total_path_length, total_gsnr;
+    int64_t total_path_index, total_modulation_level, channels_accepted, physical_services_accepted;
+    int64_t episodes_done, queue_overflow;
+} orlg_phy_episode_stats;
+
+typedef struct orlg_phy_env orlg_phy_env;
+
+/* PhyRMSAEnv.__init__ + reset(only_episode_counters=False) (phy_rmsa_env.py:30-270, 426-539) for B envs */
+int orlg_phy_create(const orlg_topology *topo, const orlg_phy_config *cfg, int32_t batch, const uint64_t *seeds,
+                    uint64_t base_seed, int32_t device, orlg_phy_env **out);
+int orlg_phy_destroy(orlg_phy_env *env);
+int orlg_phy_set_stream(orlg_phy_env *env, void *hip_stream);
+int orlg_phy_synchronize(orlg_phy_env *env);
+int orlg_phy_reset(orlg_phy_env *env, int32_t only_episode_counters);
+/* n_steps x { action = policy(env); env.step(action) } (phy_rmsa_env.py:272-351).  EXTERNAL: act_path [B] and
+ * act_channels [B][ORLG_PHY_MAX_CHANNELS] (-1 padded), n_steps == 1. */
+int orlg_phy_step(orlg_phy_env *env, int32_t policy, int32_t n_steps, const int32_t *act_path,
+                  const int16_t *act_channels, int32_t auto_reset, const orlg_phy_step_io *io);
+int orlg_phy_words_per_link(orlg_phy_env *env);
+int orlg_phy_get_requests(orlg_phy_env *env, orlg_request *out /* [B] */);
+int orlg_phy_get_counters(orlg_phy_env *env, orlg_counters *out /* [B] */);
+int orlg_phy_get_current_time(orlg_phy_env *env, double *out /* [B] */);
+int orlg_phy_get_num_running(orlg_phy_env *env, int32_t *out /* [B] */);
+int orlg_phy_get_episode_stats(orlg_phy_env *env, orlg_phy_episode_stats *out /* [B] */);
+/* topology.graph["available_channels"] as a bitmap [B][E][W] uint64 */
+int orlg_phy_get_occupancy(orlg_phy_env *env, uint64_t *out);
+int orlg_phy_reduce_counters(orlg_phy_env *env, int64_t *out /* [16] as orlg_reduce_counters */);
+
 /* host build of the device's natural-log routine (bit-identical algorithm; see csrc/orlg_math.h) */
 double orlg_host_log(double x);
 

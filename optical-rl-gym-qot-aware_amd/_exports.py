@@ -4,10 +4,11 @@ from .batched import DEFAULT_BIT_RATES, BatchedDeepRMSAEnv, BatchedRMSAEnv
 from .envs import (DeepRMSAEnv, RMSAEnv, deeprmsa_shortest_available_path_first_fit,
                    deeprmsa_shortest_path_first_fit, evaluate_heuristic, least_loaded_path_first_fit,
                    random_policy, shortest_available_path_first_fit, shortest_path_first_fit)
+from .phy import BatchedPhyRMSAEnv
 from .topology import FrozenTopology, Modulation, Path, Service, TopologyView, selection_tables
 
 __all__ = ["FrozenTopology", "Modulation", "Path", "Service", "TopologyView", "selection_tables",
-           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
+           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "BatchedPhyRMSAEnv", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
            "RMSAEnv", "DeepRMSAEnv", "shortest_path_first_fit", "shortest_available_path_first_fit",
            "least_loaded_path_first_fit", "deeprmsa_shortest_path_first_fit",
            "deeprmsa_shortest_available_path_first_fit", "random_policy", "evaluate_heuristic"]

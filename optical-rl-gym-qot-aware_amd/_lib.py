@@ -49,6 +49,25 @@ STEP_IO_DTYPES = {"act_path": "int32", "act_slot": "int32", "accepted": "uint8",
                   "network_compactness_difference": "float64", "avg_link_compactness": "float64",
                   "avg_link_utilization": "float64"}
 
+class PhyConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
+                ("k_table", C.c_int32), ("num_table_rows", C.c_int32), ("queue_capacity", C.c_int32),
+                ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
+                                          "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight")]
+
+
+class PhyStepIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("act_path", "n_channels", "channels", "accepted", "done", "request",
+                                         "arrival", "holding", "number_cuts_total", "rss_total_metric")]
+
+
+PHY_MAX_CHANNELS = 14
+PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
+                      "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
+                      "number_cuts_total": "float64", "rss_total_metric": "float64"}
+PHY_POLICIES = {"external": -1, "bmfa": 0}
+
 _lib = None
 
 
@@ -89,6 +108,17 @@ def load(build_if_missing=True):
     L.orlg_deeprmsa_observation.argtypes = [vp, vp]
     L.orlg_deeprmsa_obs_dim.argtypes = [vp]
     L.orlg_reduce_counters.argtypes = [vp, vp]
+    L.orlg_phy_create.argtypes = [C.POINTER(Topology), C.POINTER(PhyConfig), i32, vp, u64, i32, C.POINTER(vp)]
+    L.orlg_phy_destroy.argtypes = [vp]
+    L.orlg_phy_set_stream.argtypes = [vp, vp]
+    L.orlg_phy_synchronize.argtypes = [vp]
+    L.orlg_phy_reset.argtypes = [vp, i32]
+    L.orlg_phy_step.argtypes = [vp, i32, i32, vp, vp, i32, C.POINTER(PhyStepIO)]
+    L.orlg_phy_words_per_link.argtypes = [vp]
+    for name in ("orlg_phy_get_requests", "orlg_phy_get_counters", "orlg_phy_get_current_time",
+                 "orlg_phy_get_num_running", "orlg_phy_get_episode_stats", "orlg_phy_get_occupancy",
+                 "orlg_phy_reduce_counters"):
+        getattr(L, name).argtypes = [vp, vp]
     L.orlg_host_log.argtypes = [C.c_double]
     L.orlg_host_log.restype = C.c_double
     _lib = L
@@ -102,6 +132,10 @@ EXPORTED_SYMBOLS = [
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
     "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
     "orlg_host_log",
+    "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
+    "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
+    "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
+    "orlg_phy_get_occupancy", "orlg_phy_reduce_counters",
 ]
 
 

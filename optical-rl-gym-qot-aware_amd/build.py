@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liborlg.so")
 SOURCES = ["orlg_api.hip"]
-DEPS = ["orlg_api.hip", "orlg_kernels.hip", "orlg_device.h", "orlg_math.h", os.path.join("..", "..", "include", "orlg.h")]
+DEPS = ["orlg_api.hip", "orlg_kernels.hip", "orlg_phy_api.hip", "orlg_phy_kernels.hip", "orlg_device.h", "orlg_math.h", os.path.join("..", "..", "include", "orlg.h")]
 
 
 def needs_build():

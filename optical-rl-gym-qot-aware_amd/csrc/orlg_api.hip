@@ -704,3 +704,5 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
 }
 
 }  // extern "C"
+
+#include "orlg_phy_api.hip"

@@ -27,6 +27,7 @@
 // get_number_slots :708-719, is_path_free :721-734, get_available_slots :745-756, get_available_blocks
 // :774-804, _get_network_compactness :806-851, heuristics :854-937), optical_network_env.py
 // (_add_release :178-189, _get_node_pair :191-208), deeprmsa_env.py (step :48-58, observation :60-121).
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "orlg_device.h"

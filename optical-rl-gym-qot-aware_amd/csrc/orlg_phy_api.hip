@@ -1,0 +1,471 @@
+// orlg_phy_api.hip -- host side of the QoT-aware (PhyRMSA) path: orlg_phy_* entry points of include/orlg.h.
+// Included at the end of orlg_api.hip (one translation unit; shares its helpers).
+#include "orlg_phy_kernels.hip"
+
+struct orlg_phy_env {
+    OrlgPhyParams p;
+    int W, device, waves_per_block, num_paths;
+    hipStream_t stream;
+    bool own_stream;
+    size_t lds_block_bytes;
+    std::vector<void *> bufs;
+    unsigned char *staging;
+    size_t staging_bytes;
+    void *io_buf[ORLG_PHY_NUM_OUTS];
+    size_t io_cap[ORLG_PHY_NUM_OUTS];
+    int32_t *d_act_path;
+    int16_t *d_act_ch;
+};
+
+typedef void (*phy_kernel_t)(const OrlgPhyParams);
+static phy_kernel_t pick_phy(int W) {
+    switch (W) {
+        case 1: return orlg_phy_kernel<1>;
+        case 2: return orlg_phy_kernel<2>;
+        case 3: return orlg_phy_kernel<3>;
+        case 4: return orlg_phy_kernel<4>;
+        case 5: return orlg_phy_kernel<5>;
+        default: return nullptr;
+    }
+}
+
+__global__ void orlg_phy_clear_kernel(OrlgPhyParams p, int W, int keep_rng) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < (size_t)p.B * p.NW; i += nth) p.occ[i] = valid_mask(p.C, (int)(i % W));
+    for (size_t i = tid; i < (size_t)p.B; i += nth) {
+        OrlgPhyScalars s;
+        memset(&s, 0, sizeof(s));
+        s.mt_idx = keep_rng ? p.scal[i].mt_idx : ORLG_MT_N;
+        p.scal[i] = s;
+    }
+}
+
+enum { PX_REQUEST, PX_COUNTERS, PX_TIME, PX_RUNNING, PX_EPISODE };
+__global__ void orlg_phy_extract_kernel(OrlgPhyParams p, int what, unsigned char *out) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    const size_t B = p.B;
+    if (what == PX_REQUEST) {
+        orlg_request *o = reinterpret_cast<orlg_request *>(out);
+        for (size_t i = tid; i < B; i += nth) {
+            const OrlgPhyScalars &s = p.scal[i];
+            o[i].service_id = s.req_sid; o[i].src = s.req_src; o[i].dst = s.req_dst;
+            o[i].bit_rate = reinterpret_cast<const int32_t *>(p.tables + p.t_bitrates)[s.req_br];
+            o[i].arrival_time = s.req_arrival; o[i].holding_time = s.req_holding;
+        }
+    } else if (what == PX_COUNTERS) {
+        int64_t *o = reinterpret_cast<int64_t *>(out);
+        for (size_t i = tid; i < B * 8; i += nth) o[i] = p.scal[i / 8].c[i % 8];
+    } else if (what == PX_TIME) {
+        double *o = reinterpret_cast<double *>(out);
+        for (size_t i = tid; i < B; i += nth) o[i] = p.scal[i].current_time;
+    } else if (what == PX_RUNNING) {
+        int32_t *o = reinterpret_cast<int32_t *>(out);
+        for (size_t i = tid; i < B; i += nth) o[i] = p.scal[i].n_running;
+    } else if (what == PX_EPISODE) {
+        orlg_phy_episode_stats *o = reinterpret_cast<orlg_phy_episode_stats *>(out);
+        for (size_t i = tid; i < B; i += nth) {
+            const OrlgPhyScalars &s = p.scal[i];
+            o[i].total_path_length = s.total_path_length; o[i].total_gsnr = s.total_gsnr;
+            o[i].total_path_index = s.total_path_index; o[i].total_modulation_level = s.total_mod;
+            o[i].channels_accepted = s.channels_accepted; o[i].physical_services_accepted = s.physical_accepted;
+            o[i].episodes_done = s.episodes_done; o[i].queue_overflow = s.q_overflow;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScalars *scal, int B, long long *out) {
+    __shared__ long long part[256][11];
+    long long acc[11];
+    for (int q = 0; q < 11; ++q) acc[q] = 0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        for (int q = 0; q < 8; ++q) acc[q] += scal[i].c[q];
+        acc[8] += scal[i].episodes_done;
+        acc[9] += 1;
+        acc[10] += scal[i].q_overflow;
+    }
+    for (int q = 0; q < 11; ++q) part[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 11; ++q) part[threadIdx.x][q] += part[threadIdx.x + s][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x < 11 ? part[0][threadIdx.x] : 0;
+}
+
+static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
+    phy_kernel_t k = pick_phy(e->W);
+    if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)e->lds_block_bytes));
+    const int wpb = e->waves_per_block;
+    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
+    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, p);
+    HIP_TRY(hipGetLastError());
+    return ORLG_OK;
+}
+
+static int phy_extract(orlg_phy_env *e, int what, void *out, size_t bytes) {
+    if (bytes > e->staging_bytes) {
+        if (e->staging) HIP_TRY(hipFree(e->staging));
+        e->staging = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->staging), bytes));
+        e->staging_bytes = bytes;
+    }
+    hipLaunchKernelGGL(orlg_phy_extract_kernel, dim3(256), dim3(256), 0, e->stream, e->p, what, e->staging);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, e->staging, bytes, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+extern "C" {
+
+int orlg_phy_destroy(orlg_phy_env *e) {
+    if (!e) return ORLG_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (void *b : e->bufs) (void)hipFree(b);
+    if (e->staging) (void)hipFree(e->staging);
+    for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++)
+        if (e->io_buf[i]) (void)hipFree(e->io_buf[i]);
+    if (e->d_act_path) (void)hipFree(e->d_act_path);
+    if (e->d_act_ch) (void)hipFree(e->d_act_ch);
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ORLG_OK;
+}
+
+int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t batch, const uint64_t *seeds,
+                    uint64_t base_seed, int32_t device, orlg_phy_env **out) {
+    if (!t || !c || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int N = t->num_nodes, E = t->num_links, K = t->k_paths, C = c->num_channels, NBR = c->num_bit_rates;
+    if (batch < 1) return fail(ORLG_ERR_INVALID, "batch must be >= 1");
+    if (N < 2 || N > 64) return fail(ORLG_ERR_INVALID, "num_nodes %d not in 2..64", N);
+    if (E < 1 || E > 255) return fail(ORLG_ERR_INVALID, "num_links %d not in 1..255", E);
+    if (C < 1 || C > 320) return fail(ORLG_ERR_INVALID, "num_channels %d not in 1..320", C);
+    if (NBR < 1 || NBR > 64) return fail(ORLG_ERR_INVALID, "num_bit_rates %d not in 1..64", NBR);
+    if (K < 1 || K > ORLG_PHY_MAX_K) return fail(ORLG_ERR_INVALID, "k_paths %d not in 1..%d", K, ORLG_PHY_MAX_K);
+    if (c->k_table < K) return fail(ORLG_ERR_INVALID, "QoT tables have %d k-path columns, topology has k=%d", c->k_table, K);
+    if (t->num_paths < 1 || t->num_paths >= 65536) return fail(ORLG_ERR_INVALID, "num_paths out of range");
+    const int W = (C + 63) / 64;
+    if (K * W > 64) return fail(ORLG_ERR_INVALID, "k_paths * words_per_link exceeds one wavefront");
+    if (!(c->arrival_lambda > 0) || !(c->holding_lambda > 0)) return fail(ORLG_ERR_INVALID, "lambdas must be positive");
+    for (int i = 0; i < N * N; i++) {
+        int s = i / N, d = i % N;
+        if (s == d) continue;
+        if (t->pair_path_count[i] != K || t->pair_path_base[i] < 0) return fail(ORLG_ERR_INVALID, "pair (%d,%d) lacks k path records", s, d);
+        int row = c->pair_table_row[i];
+        if (row < 0 || row >= c->num_table_rows) return fail(ORLG_ERR_INVALID, "pair (%d,%d) has no QoT table row", s, d);
+        // the greedy channel order below relies on level >= 1 (a level-0 entry would sort FIRST in the reference
+        // because -np.uint8(0) == 0, SURVEY 8c caveat 3): refuse such tables instead of silently diverging
+        for (int ch = 0; ch < C; ch++)
+            for (int k = 0; k < K; k++) {
+                int lv = c->modulation_level[((size_t)row * C + ch) * c->k_table + k];
+                if (lv < 1 || lv > 31) return fail(ORLG_ERR_INVALID, "modulation level %d at row %d channel %d path %d not in 1..31", lv, row, ch, k);
+            }
+    }
+    int ndev = orlg_device_count();
+    if (ndev < 1) return fail(ORLG_ERR_NO_DEVICE, "no HIP device visible: liborlg has no CPU path");
+    if (device < 0 || device >= ndev) return fail(ORLG_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    orlg_phy_env *e = new orlg_phy_env();
+    memset(&e->p, 0, sizeof(e->p));
+    e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
+    e->d_act_path = nullptr; e->d_act_ch = nullptr; e->num_paths = t->num_paths;
+    for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
+    OrlgPhyParams &p = e->p;
+    p.B = batch; p.N = N; p.E = E; p.C = C; p.K = K; p.NBR = NBR; p.NW = E * W;
+    p.episode_length = c->episode_length; p.num_rows = c->num_table_rows; p.cpad = W * 64;
+    p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
+    // release queue: at most Poisson(load) services in progress, and never more than the channel-links can hold
+    int Q = c->queue_capacity;
+    if (Q <= 0) {
+        double load = c->arrival_lambda / c->holding_lambda;
+        double q = load + 8.0 * std::sqrt(load) + 32.0;
+        double cap = (double)E * C / 2.0 + 64.0;
+        Q = (int)(q < cap ? q : cap);
+    }
+    Q = ((Q + 63) / 64) * 64;
+    if (Q > 8192) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "queue_capacity %d too large (max 8192)", Q); }
+    p.Q = Q;
+    auto up16 = [](int v) { return (v + 15) & ~15; };
+    int off = 0;
+    p.l_occ = off; off = up16(off + p.NW * 8);
+    p.l_qtime = off; off = up16(off + Q * 8);
+    p.l_mt = off; off = up16(off + ORLG_MT_N * 4);
+    p.l_scratch = off; off = up16(off + 256 + W * 64 * 8);
+    p.l_wsc = off; off = up16(off + (int)sizeof(PhyWaveScalars));
+    p.l_wave_bytes = off;
+
+    int rc = ORLG_OK;
+#define TRY(x) do { rc = (x); if (rc) { orlg_phy_destroy(e); return rc; } } while (0)
+    {
+        std::vector<unsigned char> blob;
+        auto put = [&](const void *src, size_t bytes) {
+            size_t at = blob.size();
+            blob.resize((at + bytes + 15) & ~(size_t)15, 0);
+            memcpy(blob.data() + at, src, bytes);
+            return (int32_t)at;
+        };
+        p.t_pair = put(t->pair_path_base, (size_t)N * N * 4);
+        std::vector<OrlgPathRec> recs(t->num_paths);
+        for (int g = 0; g < t->num_paths; g++) {
+            memset(&recs[g], 0, sizeof(OrlgPathRec));
+            int h = t->path_hops[g];
+            if (h < 1 || h > ORLG_MAX_HOPS || t->path_link_off[g + 1] - t->path_link_off[g] != h) {
+                orlg_phy_destroy(e);
+                return fail(ORLG_ERR_INVALID, "path %d: hops %d not in 1..%d or CSR mismatch", g, h, ORLG_MAX_HOPS);
+            }
+            recs[g].hops = (uint8_t)h; recs[g].se = (uint8_t)t->path_se[g];
+            for (int i = 0; i < h; i++) {
+                int l = t->path_links[t->path_link_off[g] + i];
+                if (l < 0 || l >= E) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "path %d: link out of range", g); }
+                recs[g].link[i] = (uint8_t)l;
+            }
+        }
+        p.t_recs = put(recs.data(), recs.size() * sizeof(OrlgPathRec));
+        p.t_bitrates = put(c->bit_rates, (size_t)NBR * 4);
+        p.t_brcum = put(c->bit_rate_cum, (size_t)NBR * 8);
+        p.t_srccum = put(c->src_cum, (size_t)N * 8);
+        p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
+        p.t_pairrow = put(c->pair_table_row, (size_t)N * N * 4);
+        p.t_adjoff = put(c->adj_off, (size_t)(t->num_paths + 1) * 4);
+        const int nadj = c->adj_off[t->num_paths];
+        std::vector<uint16_t> adj(nadj > 0 ? nadj : 1, 0);
+        int wsum_max = 0;
+        for (int g = 0; g < t->num_paths; g++) {
+            int ws = 0;
+            for (int j = c->adj_off[g]; j < c->adj_off[g + 1]; j++) {
+                int l = c->adj_link[j], w = c->adj_weight[j];
+                if (l < 0 || l >= E || w < 1 || w > 2) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "bad cut adjacency entry %d", j); }
+                adj[j] = (uint16_t)(l | (w << 8));
+                ws += w;
+            }
+            wsum_max = ws > wsum_max ? ws : wsum_max;
+        }
+        if (wsum_max > 127) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "cut metric range %d exceeds the 8-bit score field", wsum_max); }
+        p.t_adj = put(adj.data(), adj.size() * 2);
+        std::vector<double> sq((size_t)E * E + 1);
+        for (size_t k = 0; k < sq.size(); k++) sq[k] = std::sqrt((double)k);
+        p.t_sqrt = put(sq.data(), sq.size() * 8);
+        p.t_plen = put(t->path_length, (size_t)t->num_paths * 8);
+        p.tab_bytes = (int32_t)blob.size();
+        p.l_outs = p.tab_bytes;
+        p.l_shared_bytes = p.tab_bytes + up16(ORLG_PHY_NUM_OUTS * 8);
+        unsigned char *d_blob;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_blob), blob.size()));
+        e->bufs.push_back(d_blob);
+        HIP_TRY(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        p.tables = d_blob;
+        // QoT tables re-laid [row][k-path][channel] so that the 64 lanes of a word read 64 consecutive bytes
+        std::vector<uint8_t> mt((size_t)c->num_table_rows * K * p.cpad, 0);
+        std::vector<double> gt((size_t)c->num_table_rows * K * p.cpad, 0.0);
+        for (int r = 0; r < c->num_table_rows; r++)
+            for (int ch = 0; ch < C; ch++)
+                for (int k = 0; k < K; k++) {
+                    size_t src = ((size_t)r * C + ch) * c->k_table + k, dst = ((size_t)r * K + k) * p.cpad + ch;
+                    mt[dst] = c->modulation_level[src];
+                    gt[dst] = c->gsnr[src];
+                }
+        uint8_t *d_m; double *d_g;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_m), mt.size())); e->bufs.push_back(d_m);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_g), gt.size() * 8)); e->bufs.push_back(d_g);
+        HIP_TRY(hipMemcpy(d_m, mt.data(), mt.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_g, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
+        p.mod_t = d_m; p.gsnr_t = d_g;
+    }
+    {
+        int wpb = ORLG_MAX_WAVES_PER_BLOCK;
+        while (wpb > 1 && (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 160 * 1024) wpb >>= 1;
+        if ((size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 160 * 1024) {
+            orlg_phy_destroy(e);
+            return fail(ORLG_ERR_INVALID, "tables + one environment exceed the 160 KiB LDS");
+        }
+        e->waves_per_block = wpb;
+        e->lds_block_bytes = (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes;
+    }
+    auto alloc = [&](void **ptr, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(ptr, bytes ? bytes : 16));
+        e->bufs.push_back(*ptr);
+        return ORLG_OK;
+    };
+    TRY(alloc(reinterpret_cast<void **>(&p.occ), (size_t)batch * p.NW * 8));
+    TRY(alloc(reinterpret_cast<void **>(&p.qtime), (size_t)batch * Q * 8));
+    TRY(alloc(reinterpret_cast<void **>(&p.qrec), (size_t)batch * Q * sizeof(OrlgPhySvc)));
+    TRY(alloc(reinterpret_cast<void **>(&p.mt), (size_t)batch * ORLG_MT_N * 4));
+    TRY(alloc(reinterpret_cast<void **>(&p.scal), (size_t)batch * sizeof(OrlgPhyScalars)));
+    {
+        std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
+        for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+        hipError_t er = hipMemcpy(p.mt, mt.data(), mt.size() * 4, hipMemcpyHostToDevice);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "upload of MT19937 states: %s", hipGetErrorString(er)); }
+    }
+    hipLaunchKernelGGL(orlg_phy_clear_kernel, dim3(512), dim3(256), 0, e->stream, p, W, 0);
+    OrlgPhyParams pi = p;
+    pi.mode = ORLG_MODE_INIT; pi.n_steps = 1;
+    TRY(phy_launch(e, pi));
+    {
+        hipError_t er = hipStreamSynchronize(e->stream);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "initial reset: %s", hipGetErrorString(er)); }
+    }
+#undef TRY
+    *out = e;
+    return ORLG_OK;
+}
+
+int orlg_phy_set_stream(orlg_phy_env *e, void *hip_stream) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
+    if (hip_stream) {
+        e->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    return ORLG_OK;
+}
+
+int orlg_phy_reset(orlg_phy_env *e, int32_t only_episode_counters) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    OrlgPhyParams p = e->p;
+    p.n_steps = 1;
+    if (only_episode_counters) {
+        p.mode = ORLG_MODE_EPISODE_RESET;
+    } else {
+        hipLaunchKernelGGL(orlg_phy_clear_kernel, dim3(512), dim3(256), 0, e->stream, e->p, e->W, 1);
+        HIP_TRY(hipGetLastError());
+        p.mode = ORLG_MODE_INIT;
+    }
+    return phy_launch(e, p);
+}
+
+int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_t *act_path, const int16_t *act_channels,
+                  int32_t auto_reset, const orlg_phy_step_io *io) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    if (n_steps < 1) return fail(ORLG_ERR_INVALID, "n_steps must be >= 1");
+    if (policy != ORLG_PHY_POLICY_EXTERNAL && policy != ORLG_PHY_POLICY_BMFA_CUT) return fail(ORLG_ERR_INVALID, "unknown PhyRMSA policy %d", policy);
+    if (policy == ORLG_PHY_POLICY_EXTERNAL && (!act_path || !act_channels || n_steps != 1))
+        return fail(ORLG_ERR_INVALID, "external actions need path and channel arrays and n_steps == 1");
+    HIP_TRY(hipSetDevice(e->device));
+    OrlgPhyParams p = e->p;
+    p.mode = ORLG_MODE_STEP; p.n_steps = n_steps; p.policy = policy; p.auto_reset = auto_reset;
+    if (policy == ORLG_PHY_POLICY_EXTERNAL) {
+        if (is_device_ptr(act_path) && is_device_ptr(act_channels)) {
+            p.act_path = act_path; p.act_channels = act_channels;
+        } else {
+            if (!e->d_act_path) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_act_path), (size_t)p.B * 4));
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->d_act_ch), (size_t)p.B * ORLG_PHY_MAX_CH * 2));
+            }
+            HIP_TRY(hipMemcpyAsync(e->d_act_path, act_path, (size_t)p.B * 4, hipMemcpyDefault, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->d_act_ch, act_channels, (size_t)p.B * ORLG_PHY_MAX_CH * 2, hipMemcpyDefault, e->stream));
+            p.act_path = e->d_act_path; p.act_channels = e->d_act_ch;
+        }
+    }
+    struct Slot { void *user; size_t elem; };
+    const size_t cnt = (size_t)n_steps * p.B;
+    Slot slots[ORLG_PHY_NUM_OUTS] = {
+        {io ? io->act_path : nullptr, 4},  {io ? io->n_channels : nullptr, 4}, {io ? io->channels : nullptr, 2 * ORLG_PHY_MAX_CH},
+        {io ? io->accepted : nullptr, 1},  {io ? io->done : nullptr, 1},       {io ? io->request : nullptr, 16},
+        {io ? io->arrival : nullptr, 8},   {io ? io->holding : nullptr, 8},    {io ? io->number_cuts_total : nullptr, 8},
+        {io ? io->rss_total_metric : nullptr, 8}};
+    bool staged[ORLG_PHY_NUM_OUTS] = {false};
+    p.out_mask = 0;
+    for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) {
+        p.outs[i] = nullptr;
+        if (!slots[i].user) continue;
+        p.out_mask |= 1 << i;
+        if (is_device_ptr(slots[i].user)) {
+            p.outs[i] = slots[i].user;
+        } else {
+            size_t bytes = cnt * slots[i].elem;
+            if (bytes > e->io_cap[i]) {
+                if (e->io_buf[i]) HIP_TRY(hipFree(e->io_buf[i]));
+                e->io_buf[i] = nullptr; e->io_cap[i] = 0;
+                HIP_TRY(hipMalloc(&e->io_buf[i], bytes));
+                e->io_cap[i] = bytes;
+            }
+            p.outs[i] = e->io_buf[i];
+            staged[i] = true;
+        }
+    }
+    int rc = phy_launch(e, p);
+    if (rc) return rc;
+    bool any = false;
+    for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++)
+        if (staged[i]) {
+            HIP_TRY(hipMemcpyAsync(slots[i].user, e->io_buf[i], cnt * slots[i].elem, hipMemcpyDeviceToHost, e->stream));
+            any = true;
+        }
+    if (any) HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
+int orlg_phy_synchronize(orlg_phy_env *e) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+int orlg_phy_words_per_link(orlg_phy_env *e) { return e ? e->W : ORLG_ERR_INVALID; }
+int orlg_phy_get_requests(orlg_phy_env *e, orlg_request *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return phy_extract(e, PX_REQUEST, out, (size_t)e->p.B * sizeof(orlg_request));
+}
+int orlg_phy_get_counters(orlg_phy_env *e, orlg_counters *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return phy_extract(e, PX_COUNTERS, out, (size_t)e->p.B * sizeof(orlg_counters));
+}
+int orlg_phy_get_current_time(orlg_phy_env *e, double *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return phy_extract(e, PX_TIME, out, (size_t)e->p.B * 8);
+}
+int orlg_phy_get_num_running(orlg_phy_env *e, int32_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return phy_extract(e, PX_RUNNING, out, (size_t)e->p.B * 4);
+}
+int orlg_phy_get_episode_stats(orlg_phy_env *e, orlg_phy_episode_stats *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return phy_extract(e, PX_EPISODE, out, (size_t)e->p.B * sizeof(orlg_phy_episode_stats));
+}
+int orlg_phy_get_occupancy(orlg_phy_env *e, uint64_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, e->p.occ, (size_t)e->p.B * e->p.NW * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+int orlg_phy_reduce_counters(orlg_phy_env *e, int64_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (e->staging_bytes < 16 * 8) {
+        if (e->staging) HIP_TRY(hipFree(e->staging));
+        e->staging = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->staging), 1024));
+        e->staging_bytes = 1024;
+    }
+    long long *d = reinterpret_cast<long long *>(e->staging);
+    hipLaunchKernelGGL(orlg_phy_reduce_kernel, dim3(1), dim3(256), 0, e->stream, e->p.scal, e->p.B, d);
+    HIP_TRY(hipGetLastError());
+    long long host[16];
+    HIP_TRY(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out, d, 16 * 8, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (host[10]) return fail(ORLG_ERR_QUEUE_FULL, "a release queue overflowed (capacity %d): raise queue_capacity", e->p.Q);
+    return ORLG_OK;
+}
+
+}  // extern "C"

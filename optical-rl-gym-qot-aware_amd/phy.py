@@ -1,0 +1,201 @@
+"""BatchedPhyRMSAEnv: B independent QoT-aware environments (``PhyRMSAEnv``, ``phy_rmsa_env.py:20``), physical
+layer, on one MI355X.  Constructor kwargs are the reference's (``phy_rmsa_env.py:30-58``); ``modulation_level`` /
+``gsnr`` are the ``(pairs, channels, k)`` tables and ``connections_detail`` the table's (source, destination)
+node numbers per row (an ``[rows, 2]`` int array, or the reference's MATLAB object array).
+
+Scope: ``grooming=False`` and no periodic defragmentation -- the reference's live experiment configuration
+(``tests/test_rmsa_threads_us.py:133-148``).  ``grooming=True`` / ``defrag_period`` raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .batched import COUNTER_NAMES, REQUEST_DTYPE, _ptr
+from .topology import FrozenTopology, selection_tables
+
+PHY_DEFAULT_BIT_RATES = (100, 200, 300, 400, 500, 600)  # phy_rmsa_env.py:38
+
+EPISODE_STATS_DTYPE = np.dtype([("total_path_length", np.float64), ("total_gsnr", np.float64),
+                                ("total_path_index", np.int64), ("total_modulation_level", np.int64),
+                                ("channels_accepted", np.int64), ("physical_services_accepted", np.int64),
+                                ("episodes_done", np.int64), ("queue_overflow", np.int64)])
+
+
+def _pairs_from_connections_detail(cd):
+    cd = np.asarray(cd)
+    if cd.dtype == object:  # scipy.io.loadmat cell array: column 0 / 1 hold 1x1 arrays
+        return np.array([[int(np.asarray(r[0]).ravel()[0]), int(np.asarray(r[1]).ravel()[0])] for r in cd], np.int32)
+    return np.ascontiguousarray(cd[:, :2], dtype=np.int32)
+
+
+class BatchedPhyRMSAEnv:
+    def __init__(self, topology, batch_size: int, *, modulation_level, connections_detail, gsnr,
+                 episode_length: int = 1000, load: float = 10, mean_service_holding_time: float = 10800.0,
+                 bit_rates: Sequence[int] = PHY_DEFAULT_BIT_RATES, bit_rate_probabilities=None,
+                 node_request_probabilities=None, seed: Optional[int] = None, seeds=None,
+                 allow_rejection: bool = False, number_spectrum_channels: int = 80,
+                 number_spectrum_channels_s_band: int = 108, l_band: bool = True, s_band: bool = True,
+                 defrag_period=None, number_moves=None, metric: str = "cut", grooming: bool = False,
+                 queue_capacity: int = 0, device: int = 0, **_ignored):
+        if grooming:
+            raise NotImplementedError("the virtual (grooming) layer is not on the device path yet")
+        if defrag_period:
+            raise NotImplementedError("periodic defragmentation is not on the device path yet")
+        self.L = _lib.load()
+        self.topology = FrozenTopology.from_graph(topology)
+        t = self.topology
+        self.batch_size = int(batch_size)
+        self.episode_length = int(episode_length)
+        self.k_paths = t.k_paths
+        self.bit_rates = [int(b) for b in bit_rates]
+        self.allow_rejection = bool(allow_rejection)
+        # optical_network_env.py:78-102
+        if s_band:
+            self.num_channels = 2 * number_spectrum_channels + number_spectrum_channels_s_band
+        elif l_band:
+            self.num_channels = 2 * number_spectrum_channels
+        else:
+            self.num_channels = number_spectrum_channels
+        self.load, self.mean_service_holding_time = load, mean_service_holding_time
+        self.mean_service_inter_arrival_time = 1 / float(load / float(mean_service_holding_time))
+        self.node_request_probabilities, src_cum, dst_cum, br_cum = selection_tables(
+            node_request_probabilities, bit_rate_probabilities, t.num_nodes, self.bit_rates)
+        self.rand_seed = 41 if seed is None else int(seed)
+        mod = np.ascontiguousarray(modulation_level, dtype=np.uint8)
+        gs = np.ascontiguousarray(gsnr, dtype=np.float64)
+        assert mod.shape == gs.shape and mod.shape[1] >= self.num_channels
+        if mod.shape[1] != self.num_channels:
+            mod, gs = np.ascontiguousarray(mod[:, :self.num_channels]), np.ascontiguousarray(gs[:, :self.num_channels])
+        pairs = _pairs_from_connections_detail(connections_detail)
+        adj_off, adj_link, adj_weight = t.cut_adjacency()
+
+        self._keep = []
+
+        def keep(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            self._keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+
+        ct = _lib.Topology()
+        ct.num_nodes, ct.num_links, ct.k_paths, ct.num_paths = t.num_nodes, t.num_links, t.k_paths, t.num_paths
+        for name, dt in (("pair_path_base", np.int32), ("pair_path_count", np.int32), ("path_hops", np.int32),
+                         ("path_se", np.int32), ("path_length", np.float64), ("path_link_off", np.int32),
+                         ("path_links", np.int32)):
+            setattr(ct, name, keep(getattr(t, name), dt))
+        cc = _lib.PhyConfig()
+        cc.num_channels, cc.episode_length, cc.num_bit_rates = self.num_channels, self.episode_length, len(self.bit_rates)
+        cc.k_table, cc.num_table_rows, cc.queue_capacity = mod.shape[2], mod.shape[0], int(queue_capacity)
+        cc.arrival_lambda = 1 / self.mean_service_inter_arrival_time
+        cc.holding_lambda = 1 / self.mean_service_holding_time
+        cc.bit_rates = keep(self.bit_rates, np.int32)
+        cc.bit_rate_cum = keep(br_cum, np.float64)
+        cc.src_cum = keep(src_cum, np.float64)
+        cc.dst_cum = keep(dst_cum, np.float64)
+        cc.pair_table_row = keep(t.pair_table_rows(pairs), np.int32)
+        cc.modulation_level = keep(mod, np.uint8)
+        cc.gsnr = keep(gs, np.float64)
+        cc.adj_off, cc.adj_link, cc.adj_weight = keep(adj_off, np.int32), keep(adj_link, np.int32), keep(adj_weight, np.int32)
+        seeds_ptr = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            seeds_ptr = seeds.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        _lib.check(self.L.orlg_phy_create(C.byref(ct), C.byref(cc), self.batch_size, seeds_ptr,
+                                          C.c_uint64(self.rand_seed), int(device), C.byref(h)))
+        self.h = h
+        self.words_per_link = self.L.orlg_phy_words_per_link(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orlg_phy_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self.L.orlg_phy_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        _lib.check(self.L.orlg_phy_synchronize(self.h))
+
+    def reset(self, only_episode_counters: bool = True):
+        _lib.check(self.L.orlg_phy_reset(self.h, 1 if only_episode_counters else 0))
+
+    def run(self, policy: str, n_steps: int = 1, *, act_path=None, act_channels=None, auto_reset: bool = False,
+            outputs: Sequence[str] = ()):
+        """``n_steps`` x (policy -> PhyRMSAEnv.step).  ``policy='external'``: ``act_path`` [B] int32 (-2 = blocked)
+        and ``act_channels`` [B, 14] int16 (-1 padded).  Returns the requested per-step arrays [n_steps, B(, ...)]."""
+        B = self.batch_size
+        io = _lib.PhyStepIO()
+        res = {}
+        for name in outputs:
+            shape = {"request": (n_steps, B, 4), "channels": (n_steps, B, _lib.PHY_MAX_CHANNELS)}.get(name, (n_steps, B))
+            res[name] = np.zeros(shape, dtype=_lib.PHY_STEP_IO_DTYPES[name])
+            setattr(io, name, _ptr(res[name]))
+        ap = ac = None
+        if act_path is not None:
+            act_path = np.ascontiguousarray(act_path, np.int32)
+            act_channels = np.ascontiguousarray(act_channels, np.int16)
+            assert act_channels.shape == (B, _lib.PHY_MAX_CHANNELS)
+            ap, ac = _ptr(act_path), _ptr(act_channels)
+        _lib.check(self.L.orlg_phy_step(self.h, _lib.PHY_POLICIES[policy], int(n_steps), ap, ac,
+                                        1 if auto_reset else 0, C.byref(io)))
+        return res
+
+    def requests(self):
+        a = np.zeros(self.batch_size, REQUEST_DTYPE)
+        _lib.check(self.L.orlg_phy_get_requests(self.h, _ptr(a)))
+        return a
+
+    def counters(self):
+        a = np.zeros((self.batch_size, 8), np.int64)
+        _lib.check(self.L.orlg_phy_get_counters(self.h, _ptr(a)))
+        return {n: a[:, i].copy() for i, n in enumerate(COUNTER_NAMES)}
+
+    def current_time(self):
+        a = np.zeros(self.batch_size, np.float64)
+        _lib.check(self.L.orlg_phy_get_current_time(self.h, _ptr(a)))
+        return a
+
+    def num_running(self):
+        a = np.zeros(self.batch_size, np.int32)
+        _lib.check(self.L.orlg_phy_get_num_running(self.h, _ptr(a)))
+        return a
+
+    def episode_stats(self):
+        a = np.zeros(self.batch_size, EPISODE_STATS_DTYPE)
+        _lib.check(self.L.orlg_phy_get_episode_stats(self.h, _ptr(a)))
+        return a
+
+    def info(self):
+        """The per-episode ratios of the info dict (``phy_rmsa_env.py:339-347``) for every env."""
+        s = self.episode_stats()
+        phys, chans = s["physical_services_accepted"], s["channels_accepted"]
+        return {"total_path_length": s["total_path_length"] / (phys + 1),
+                "avrage_gsnr": s["total_gsnr"] / (chans + 1),
+                "average_mod_level": s["total_modulation_level"] / (chans + 1),
+                "average_path_index": s["total_path_index"] / (phys + 1),
+                "path_index": s["total_path_index"], "physical_paths": phys}
+
+    def available_channels(self):
+        """topology.graph["available_channels"] for every env: [B, E, C] uint8 (1 = free)."""
+        E, W = self.topology.num_links, self.words_per_link
+        w = np.zeros((self.batch_size, E, W), np.uint64)
+        _lib.check(self.L.orlg_phy_get_occupancy(self.h, _ptr(w)))
+        bits = np.unpackbits(w.view(np.uint8), axis=-1, bitorder="little")
+        return bits.reshape(self.batch_size, E, -1)[:, :, :self.num_channels]
+
+    def reduce_counters(self):
+        a = np.zeros(16, np.int64)
+        _lib.check(self.L.orlg_phy_reduce_counters(self.h, _ptr(a)))
+        d = {n: int(a[i]) for i, n in enumerate(COUNTER_NAMES)}
+        d["episodes_done"], d["num_envs"] = int(a[8]), int(a[9])
+        return d, a
