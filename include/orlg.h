@@ -246,6 +246,25 @@ int orlg_phy_get_episode_stats(orlg_phy_env *env, orlg_phy_episode_stats *out /*
 int orlg_phy_get_occupancy(orlg_phy_env *env, uint64_t *out);
 int orlg_phy_reduce_counters(orlg_phy_env *env, int64_t *out /* [16] as orlg_reduce_counters */);
 
+/* ------------------------------------------------------------------------------------------------
+ * GN-model GSNR admission check: calculate_osnr (examples/calculate_osnr.py:9-56) for a flattened batch of checks.
+ * Check m walks links check_link_off[m]..check_link_off[m+1]; link l has spans link_span_off[l].. and the services
+ * running on it link_svc_off[l].. in list order (svc_is_self marks the entry that is the current service itself: the
+ * reference adds a stale phi for it, calculate_osnr.py:31-46).  Units: Hz, W, km, 1/m (attenuation_normalized),
+ * linear noise figure.  Result: GSNR in dB.  Arrays may be host or device pointers.  Orphaned in the reference
+ * (no caller / test): parity is pinned only by tests/golden/osnr_grid.npz.
+ */
+typedef struct orlg_osnr_batch {
+    int32_t num_checks, num_links, num_spans, num_services;
+    const int32_t *check_link_off, *link_span_off, *link_svc_off;
+    const double *bandwidth, *center_frequency, *launch_power;            /* [num_checks] */
+    const double *span_length_km, *span_attenuation, *span_noise_figure;  /* [num_spans] */
+    const double *svc_bandwidth, *svc_center_frequency;                   /* [num_services] */
+    const int32_t *svc_se;                                                /* [num_services] 1..6 */
+    const uint8_t *svc_is_self;                                           /* [num_services] */
+} orlg_osnr_batch;
+int orlg_gn_osnr(const orlg_osnr_batch *batch, double *gsnr_db /* [num_checks] */, int32_t device, void *hip_stream);
+
 /* host build of the device's natural-log routine (bit-identical algorithm; see csrc/orlg_math.h) */
 double orlg_host_log(double x);
 

@@ -135,7 +135,7 @@ EXPORTED_SYMBOLS = [
     "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
-    "orlg_phy_get_occupancy", "orlg_phy_reduce_counters",
+    "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_gn_osnr",
 ]
 
 

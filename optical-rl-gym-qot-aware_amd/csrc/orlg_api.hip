@@ -706,3 +706,4 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
 }  // extern "C"
 
 #include "orlg_phy_api.hip"
+#include "orlg_osnr.hip"

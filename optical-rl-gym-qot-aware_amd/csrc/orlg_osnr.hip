@@ -1,0 +1,132 @@
+// orlg_osnr.hip -- GN-model GSNR admission check (examples/calculate_osnr.py:9-56) as a HIP kernel + its C entry point.
+// Included at the end of orlg_api.hip.  One wavefront per admission check; lanes run over the interferers of a link.
+//
+// The reference routine is sequential and carries a quirk that is reproduced here: `sum_phi += phi` also executes for
+// the list entry that IS the current service, adding the stale `phi` of the entry visited before it (the previous
+// list element; for a self entry at the head of the list the last interferer of the previous span / link iteration,
+// initially 0) -- calculate_osnr.py:16,31-46.  The lane-parallel sum adds the same terms in a different order, which
+// moves the result by a few 1e-16 relative (north_star tolerance: 1e-6 relative).  PARITY UNPINNED by the reference
+// (no caller, no test, not importable: SURVEY 0.3 / 8c); checked against tests/golden/osnr_grid.npz and the oracle.
+#pragma once
+#include "orlg_kernels.hip"
+
+struct OrlgOsnrDev {
+    int32_t num_checks;
+    const int32_t *check_link_off, *link_span_off, *link_svc_off;
+    const double *bandwidth, *center_frequency, *launch_power;
+    const double *span_length_km, *span_attenuation, *span_noise_figure;
+    const double *svc_bandwidth, *svc_center_frequency;
+    const int32_t *svc_se;
+    const uint8_t *svc_is_self;
+    double *out;
+};
+
+DEV double osnr_phi(double sb, double sf, int se, double fc, double l_eff_a, double l_eff, double len) {
+    const double beta_2 = -21.3e-27, pi = 3.141592653589793;
+    const double pmf[6] = {1, 1, 2.0 / 3, 17.0 / 25, 69.0 / 100, 13.0 / 21};
+    double pm = se == 1 ? pmf[0] : se == 2 ? pmf[1] : se == 3 ? pmf[2] : se == 4 ? pmf[3] : se == 5 ? pmf[4] : pmf[5];
+    return (asinh(pi * pi * fabs(beta_2) * l_eff_a * sb * (sf - fc + (sb / 2))) -
+            asinh(pi * pi * fabs(beta_2) * l_eff_a * sb * (sf - fc - (sb / 2)))) -
+           (pm * (sb / fabs(sf - fc)) * 5 / 3 * (l_eff / (len * 1e3)));
+}
+
+__global__ __launch_bounds__(256) void orlg_gn_osnr_kernel(const OrlgOsnrDev b) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (m >= b.num_checks) return;
+    const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = 3.141592653589793;
+    const double bw = b.bandwidth[m], fc = b.center_frequency[m], pw = b.launch_power[m];
+    double acc_gsnr = 0.0, phi_carry = 0.0;
+    for (int l = b.check_link_off[m]; l < b.check_link_off[m + 1]; l++) {
+        const int i0 = b.link_svc_off[l], i1 = b.link_svc_off[l + 1];
+        // position of the current service in this link's list (-1: absent)
+        int self_idx = -1;
+        for (int c0 = i0; c0 < i1 && self_idx < 0; c0 += 64) {
+            const int i = c0 + lane;
+            u64 mk = ballot(i < i1 && b.svc_is_self[i]);
+            if (mk) self_idx = c0 + ctz64(mk);
+        }
+        const int last_idx = (i1 - 1 == self_idx) ? i1 - 2 : i1 - 1;  // last interferer that is not the service itself
+        const bool has_other = last_idx >= i0;
+        for (int s = b.link_span_off[l]; s < b.link_span_off[l + 1]; s++) {
+            const double att = b.span_attenuation[s], len = b.span_length_km[s], nf = b.span_noise_figure[s];
+            const double l_eff_a = 1 / (2 * att);
+            const double l_eff = (1 - exp(-2 * att * len * 1e3)) / (2 * att);
+            double part = 0.0;
+            for (int i = i0 + lane; i < i1; i += 64)
+                if (i != self_idx)
+                    part += osnr_phi(b.svc_bandwidth[i], b.svc_center_frequency[i], b.svc_se[i], fc, l_eff_a, l_eff, len);
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            double sum_phi = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4 * att)) + part;
+            if (self_idx >= 0) {
+                // the stale phi the reference adds for the service's own list entry
+                const int prev = self_idx - 1;
+                sum_phi += prev >= i0 ? osnr_phi(b.svc_bandwidth[prev], b.svc_center_frequency[prev], b.svc_se[prev], fc,
+                                                 l_eff_a, l_eff, len)
+                                      : phi_carry;
+            }
+            if (has_other)
+                phi_carry = osnr_phi(b.svc_bandwidth[last_idx], b.svc_center_frequency[last_idx], b.svc_se[last_idx], fc,
+                                     l_eff_a, l_eff, len);
+            const double r = pw / bw;
+            const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sum_phi * bw;
+            const double power_ase = bw * h_plank * fc * (exp(2 * att * len * 1e3) - 1) * nf;
+            acc_gsnr += 1 / (pw / (power_ase + power_nli_span));
+        }
+    }
+    if (lane == 0) b.out[m] = 10 * log10(1 / acc_gsnr);
+}
+
+extern "C" int orlg_gn_osnr(const orlg_osnr_batch *q, double *gsnr_db, int32_t device, void *hip_stream) {
+    if (!q || !gsnr_db) return fail(ORLG_ERR_INVALID, "null argument");
+    if (q->num_checks < 0 || q->num_links < 0 || q->num_spans < 0 || q->num_services < 0) return fail(ORLG_ERR_INVALID, "negative size");
+    int ndev = orlg_device_count();
+    if (ndev < 1) return fail(ORLG_ERR_NO_DEVICE, "no HIP device visible: liborlg has no CPU path");
+    if (device < 0 || device >= ndev) return fail(ORLG_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    if (q->num_checks == 0) return ORLG_OK;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    std::vector<void *> tmp;
+    auto cleanup = [&]() { for (void *t : tmp) (void)hipFree(t); };
+    auto on_device = [&](const void *ptr, size_t bytes, const void **out) -> int {
+        if (bytes == 0 || is_device_ptr(ptr)) { *out = ptr; return ORLG_OK; }
+        void *d = nullptr;
+        hipError_t er = hipMalloc(&d, bytes);
+        if (er != hipSuccess) return fail(ORLG_ERR_HIP, "hipMalloc: %s", hipGetErrorString(er));
+        tmp.push_back(d);
+        er = hipMemcpyAsync(d, ptr, bytes, hipMemcpyHostToDevice, stream);
+        if (er != hipSuccess) return fail(ORLG_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(er));
+        *out = d;
+        return ORLG_OK;
+    };
+    OrlgOsnrDev b;
+    b.num_checks = q->num_checks;
+    int rc = ORLG_OK;
+    const size_t M = q->num_checks, L = q->num_links, S = q->num_spans, V = q->num_services;
+#define ONDEV(field, count, type) \
+    if (!rc) { const void *p_ = nullptr; rc = on_device(q->field, (size_t)(count) * sizeof(type), &p_); b.field = static_cast<const type *>(p_); }
+    ONDEV(check_link_off, M + 1, int32_t) ONDEV(link_span_off, L + 1, int32_t) ONDEV(link_svc_off, L + 1, int32_t)
+    ONDEV(bandwidth, M, double) ONDEV(center_frequency, M, double) ONDEV(launch_power, M, double)
+    ONDEV(span_length_km, S, double) ONDEV(span_attenuation, S, double) ONDEV(span_noise_figure, S, double)
+    ONDEV(svc_bandwidth, V, double) ONDEV(svc_center_frequency, V, double) ONDEV(svc_se, V, int32_t)
+    ONDEV(svc_is_self, V, uint8_t)
+#undef ONDEV
+    if (rc) { cleanup(); return rc; }
+    double *d_out = gsnr_db;
+    const bool out_dev = is_device_ptr(gsnr_db);
+    if (!out_dev) {
+        void *d = nullptr;
+        hipError_t er = hipMalloc(&d, M * 8);
+        if (er != hipSuccess) { cleanup(); return fail(ORLG_ERR_HIP, "hipMalloc: %s", hipGetErrorString(er)); }
+        tmp.push_back(d);
+        d_out = static_cast<double *>(d);
+    }
+    b.out = d_out;
+    hipLaunchKernelGGL(orlg_gn_osnr_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, b);
+    hipError_t er = hipGetLastError();
+    if (er == hipSuccess && !out_dev) er = hipMemcpyAsync(gsnr_db, d_out, M * 8, hipMemcpyDeviceToHost, stream);
+    if (er == hipSuccess && (!out_dev || !tmp.empty())) er = hipStreamSynchronize(stream);
+    cleanup();
+    if (er != hipSuccess) return fail(ORLG_ERR_HIP, "GN OSNR launch: %s", hipGetErrorString(er));
+    return ORLG_OK;
+}

@@ -424,3 +424,37 @@ class PhyOracleEnv:
                 setattr(tr, name, _ptr(out[name]))
         self.L.orc_phy_run(self.h, PHY_POLICY[policy], int(n_steps), 1 if reset_on_done else 0, C.byref(tr))
         return out
+
+
+# ----------------------------------------------------------------------------------------- GN-model OSNR oracle
+class OsnrBatch(C.Structure):
+    _fields_ = [("num_checks", C.c_int32), ("num_links", C.c_int32), ("num_spans", C.c_int32), ("num_services", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("check_link_off", "link_span_off", "link_svc_off", "bandwidth", "center_frequency",
+                                          "launch_power", "span_length_km", "span_attenuation", "span_noise_figure",
+                                          "svc_bandwidth", "svc_center_frequency", "svc_se", "svc_is_self")]
+
+
+OSNR_FIELDS = (("check_link_off", np.int32), ("link_span_off", np.int32), ("link_svc_off", np.int32),
+               ("bandwidth", np.float64), ("center_frequency", np.float64), ("launch_power", np.float64),
+               ("span_length_km", np.float64), ("span_attenuation", np.float64), ("span_noise_figure", np.float64),
+               ("svc_bandwidth", np.float64), ("svc_center_frequency", np.float64), ("svc_se", np.int32),
+               ("svc_is_self", np.uint8))
+
+
+def gn_osnr(arrays):
+    """GSNR [dB] for a flattened batch of admission checks (dict of arrays, see orlg_oracle_osnr.h)."""
+    L = lib()
+    L.orc_gn_osnr.argtypes = [C.POINTER(OsnrBatch), C.c_void_p]
+    b = OsnrBatch()
+    keep = []
+    for name, dt in OSNR_FIELDS:
+        a = np.ascontiguousarray(arrays[name], dtype=dt)
+        keep.append(a)
+        setattr(b, name, _ptr(a))
+    b.num_checks = len(arrays["bandwidth"])
+    b.num_links = len(arrays["link_span_off"]) - 1
+    b.num_spans = len(arrays["span_length_km"])
+    b.num_services = len(arrays["svc_bandwidth"])
+    out = np.zeros(b.num_checks)
+    L.orc_gn_osnr(C.byref(b), _ptr(out))
+    return out

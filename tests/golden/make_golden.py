@@ -475,6 +475,90 @@ def gen_phy():
               "running", int(out["n_running"].max()), "cuts", out["number_cuts_total"][-1])
 
 
+# --------------------------------------------------------------------------- GN-model OSNR grid
+def gen_osnr():
+    """examples/calculate_osnr.py cannot be imported (it imports names that do not exist), has no caller
+    and no test.  Its function body is self-contained arithmetic on duck-typed objects: the function text is executed
+    here with the two broken import statements dropped, on SimpleNamespace inputs.  Only inputs and outputs are kept."""
+    from types import SimpleNamespace as NS
+
+    src = open(os.path.join(REF, "examples", "calculate_osnr.py")).read()
+    keep = []
+    for ln in src.splitlines():
+        if ln.startswith("from optical_rl_gym.utils import"):
+            continue  # imports Span / Link, which do not exist (utils.py:38-54 are commented out)
+        if "prmsa_env" in ln and "import" in ln:
+            ln = ln[: len(ln) - len(ln.lstrip())] + "pass"  # `from optical_rl_gym.envs.prmsa_env import PRMSAEnv`: no such module
+        keep.append(ln)
+    ns = {"Service": object}  # only used as an annotation in the signature
+    exec(compile("\n".join(keep), "calculate_osnr_text", "exec"), ns)
+    calc = ns["calculate_osnr"]
+
+    rng = np.random.default_rng(2024)
+    M = 300
+    check_link_off, link_span_off, link_svc_off = [0], [0], [0]
+    bandwidth, center, power = [], [], []
+    span_len, span_att, span_nf = [], [], []
+    svc_bw, svc_fc, svc_se, svc_self = [], [], [], []
+    out = []
+    grid_fc = 191.3e12 + 50e9 * np.arange(268)
+    for m in range(M):
+        nlinks = int(rng.integers(1, 8))
+        cur = NS(service_id=1000, bandwidth=float(rng.choice([37.5e9, 50e9, 75e9])),
+                 center_frequency=float(grid_fc[rng.integers(0, 268)]), launch_power=float(10 ** (rng.uniform(-3, 1) / 10) * 1e-3))
+        links, topo = [], {}
+        for li in range(nlinks):
+            nspans = int(rng.integers(1, 12))
+            att_db_km = float(rng.uniform(0.18, 0.25))
+            spans = []
+            for _ in range(nspans):
+                length = float(rng.uniform(40, 80))
+                spans.append(NS(length=length, attenuation_normalized=att_db_km / (2 * 10 * np.log10(np.exp(1)) * 1e3),
+                                noise_figure_normalized=float(10 ** (rng.uniform(4.5, 6.5) / 10))))
+            nsvc = int(rng.integers(0, 60)) if m % 7 else int(rng.integers(150, 267))
+            chans = rng.choice(268, size=nsvc, replace=False)
+            running = []
+            for sid, c in enumerate(chans):
+                f = float(grid_fc[c])
+                if f == cur.center_frequency:
+                    continue
+                running.append(NS(service_id=sid, bandwidth=float(rng.choice([37.5e9, 50e9])), center_frequency=f,
+                                  current_modulation=NS(spectral_efficiency=int(rng.integers(1, 7)))))
+            if rng.random() < 0.8:  # the current service is usually in the link's running list too
+                running.insert(int(rng.integers(0, len(running) + 1)), cur)
+            n1, n2 = f"a{li}", f"b{li}"
+            topo.setdefault(n1, {})[n2] = {"link": NS(spans=spans), "running_services": running}
+            links.append(NS(node1=n1, node2=n2))
+            for s in spans:
+                span_len.append(s.length); span_att.append(s.attenuation_normalized); span_nf.append(s.noise_figure_normalized)
+            link_span_off.append(len(span_len))
+            for s in running:
+                is_self = s is cur
+                svc_bw.append(s.bandwidth); svc_fc.append(s.center_frequency)
+                svc_se.append(1 if is_self else s.current_modulation.spectral_efficiency); svc_self.append(is_self)
+            link_svc_off.append(len(svc_bw))
+        check_link_off.append(len(link_span_off) - 1)
+        cur.path = NS(links=links)
+        bandwidth.append(cur.bandwidth); center.append(cur.center_frequency); power.append(cur.launch_power)
+        out.append(float(calc(NS(topology=topo), cur)))
+    np.savez_compressed(
+        os.path.join(HERE, "osnr_grid.npz"),
+        check_link_off=np.array(check_link_off, np.int32), link_span_off=np.array(link_span_off, np.int32),
+        link_svc_off=np.array(link_svc_off, np.int32), bandwidth=np.array(bandwidth), center_frequency=np.array(center),
+        launch_power=np.array(power), span_length_km=np.array(span_len), span_attenuation=np.array(span_att),
+        span_noise_figure=np.array(span_nf), svc_bandwidth=np.array(svc_bw), svc_center_frequency=np.array(svc_fc),
+        svc_se=np.array(svc_se, np.int32), svc_is_self=np.array(svc_self, np.uint8), gsnr_db=np.array(out))
+    print("osnr grid:", M, "checks,", len(span_len), "spans,", len(svc_bw), "interferer entries; GSNR range",
+          min(out), max(out))
+    # SURVEY 8c known answer: 2 x 75 km spans, 1 interferer at +100 GHz, 50 GHz, 0 dBm
+    att = 0.2 / (2 * 10 * np.log10(np.exp(1)) * 1e3)
+    cur = NS(service_id=1, bandwidth=50e9, center_frequency=193.1e12, launch_power=1e-3)
+    oth = NS(service_id=2, bandwidth=50e9, center_frequency=193.2e12, current_modulation=NS(spectral_efficiency=2))
+    spans = [NS(length=75.0, attenuation_normalized=att, noise_figure_normalized=10 ** 0.55) for _ in range(2)]
+    cur.path = NS(links=[NS(node1="a", node2="b")])
+    print("known answer:", calc(NS(topology={"a": {"b": {"link": NS(spans=spans), "running_services": [cur, oth]}}}), cur))
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()

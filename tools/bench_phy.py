@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: BASELINE.json configs[2] -- QoT-aware RMSA (PhyRMSA) on US14, batch 4096, bmfa(cut) heuristic
+on the device.  Prints one JSON line (env steps/s).  usage: python tools/bench_phy.py [--batch B] [--steps K] [--load L]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=3000)
+    ap.add_argument("--chunk", type=int, default=250)
+    ap.add_argument("--load", type=float, default=1400)
+    ap.add_argument("--metrics", action="store_true", help="also compute number_cuts_total / rss_total_metric every step")
+    args = ap.parse_args()
+    import torch
+    from conftest import load_phy_tables, load_topology
+    from optical_rl_gym_amd import BatchedPhyRMSAEnv
+    topo = load_topology("us14_3-paths_6-modulations")
+    pairs, mod, gsnr = load_phy_tables("us14_k3")
+    env = BatchedPhyRMSAEnv(topo, args.batch, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=args.load,
+                            mean_service_holding_time=25, episode_length=200, seed=10)
+    outs = ("number_cuts_total", "rss_total_metric") if args.metrics else ()
+
+    def run(k):
+        left = k
+        while left > 0:
+            n = min(left, args.chunk)
+            env.run("bmfa", n, auto_reset=True, outputs=outs)
+            left -= n
+    run(args.warmup)
+    env.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    env.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    red, _ = env.reduce_counters()
+    print(json.dumps({"metric": "env steps/s, PhyRMSA US14 bmfa(cut)", "value": args.batch * args.steps / dt,
+                      "batch": args.batch, "steps": args.steps, "load": args.load, "metrics_every_step": args.metrics,
+                      "ms_per_step": dt * 1e3 / args.steps, "mean_running": float(env.num_running().mean()),
+                      "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / red["services_processed"]}))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
