@@ -1,0 +1,33 @@
+"""PhyRMSAEnv single-env view driven by a heuristic callback on the reference's surface vs the reference's trace."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_phy_tables, load_topology
+
+pytestmark = pytest.mark.gpu
+
+
+def test_phy_view_bmfa_matches_reference():
+    import optical_rl_gym_amd as pkg
+    z, meta = load_golden("phy_us14_s10_bmfa")
+    pairs, mod, gsnr = load_phy_tables(meta["tables"])
+    env = pkg.PhyRMSAEnv(topology=load_topology(meta["topology"]), modulation_level=mod, connections_detail=pairs,
+                         gsnr=gsnr, **meta["env_kwargs"])
+    assert env.topology.graph["num_channel_resources"] == 268
+    for t in range(90):
+        s = env.current_service
+        assert (s.source_id, s.destination_id, s.bit_rate) == (z["src_id"][t], z["dst_id"][t], z["bit_rate"][t])
+        a = pkg.phy_aware_bmfa_rmsa(env)
+        assert a[0] == z["act_path"][t] and len(a[1]) == z["n_channels"][t], t
+        assert [c[0] for c in a[1]] == z["channels"][t][:len(a[1])].tolist()
+        assert [c[1] for c in a[1]] == z["ch_used"][t][:len(a[1])].tolist()
+        obs, reward, done, truncated, info = env.step(a)
+        assert truncated is False and reward == z["reward"][t] and done == bool(z["done"][t])
+        assert info["number_cuts_total"] == z["number_cuts_total"][t]
+        assert info["rss_total_metric"] == z["rss_total_metric"][t]
+        assert info["total_path_length"] == z["total_path_length"][t]
+        np.testing.assert_allclose(info["avrage_gsnr"], z["avrage_gsnr"][t], rtol=1e-15)
+        assert info["path_index"] == z["path_index"][t] and info["physical_paths"] == z["physical_paths"][t]
+        assert info["episode_service_blocking_rate"] == z["episode_service_blocking_rate"][t]
+        assert info["bit_rate_blocking_rate"] == z["bit_rate_blocking_rate"][t]
+    env.close()
