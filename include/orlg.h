@@ -132,6 +132,9 @@ int orlg_destroy(orlg_env *env);
 /* use an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own */
 int orlg_set_stream(orlg_env *env, void *hip_stream);
 int orlg_synchronize(orlg_env *env);
+/* launch geometry of the step kernel: out[0] environments (waves) per workgroup, out[1] LDS bytes per workgroup,
+ * out[2] resident workgroups per CU (occupancy query), out[3] 64-bit words per link */
+int orlg_launch_info(orlg_env *env, int32_t *out /* [4] */);
 
 /* RMSAEnv.reset(only_episode_counters) (rmsa_env.py:343-457), all envs */
 int orlg_reset(orlg_env *env, int32_t only_episode_counters);

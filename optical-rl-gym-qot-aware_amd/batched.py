@@ -124,6 +124,13 @@ class BatchedRMSAEnv:
     def synchronize(self):
         _lib.check(self.L.orlg_synchronize(self.h))
 
+    def launch_info(self):
+        """Launch geometry of the step kernel (envs per workgroup, LDS bytes, resident workgroups per CU)."""
+        a = np.zeros(4, np.int32)
+        _lib.check(self.L.orlg_launch_info(self.h, _ptr(a)))
+        return {"envs_per_workgroup": int(a[0]), "lds_bytes_per_workgroup": int(a[1]),
+                "workgroups_per_cu": int(a[2]), "words_per_link": int(a[3])}
+
     # ------------------------------------------------------------------ stepping
     def reset(self, only_episode_counters: bool = True):
         _lib.check(self.L.orlg_reset(self.h, 1 if only_episode_counters else 0))

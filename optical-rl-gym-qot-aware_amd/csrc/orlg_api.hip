@@ -106,6 +106,9 @@ __global__ void orlg_clear_state_kernel(OrlgParams p, int W, int keep_rng) {
         OrlgEnvScalars s;
         memset(&s, 0, sizeof(s));
         s.mt_idx = keep_rng ? p.scal[i].mt_idx : ORLG_MT_N;
+        // pre-generated arrivals are part of the RNG stream: a full reset keeps them
+        s.ring_pos = keep_rng ? p.scal[i].ring_pos : 0;
+        s.ring_cnt = keep_rng ? p.scal[i].ring_cnt : 0;
         p.scal[i] = s;
     }
 }
@@ -327,13 +330,15 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     p.obs_dim = 1 + 2 * N + (2 * c->j + 3) * K;
     p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
     // release-queue capacity: offered load in Erlang = arrival_lambda / holding_lambda; the number of
-    // services in progress is at most Poisson(load) distributed -> mean + 8 sigma + slack, whole waves
+    // services in progress is at most Poisson(load) distributed -> mean + 10 sigma, whole waves (an overflow is
+    // detected and reported, never silent)
     int Q = c->queue_capacity;
     if (Q <= 0) {
         double load = c->arrival_lambda / c->holding_lambda;
-        Q = (int)(load + 8.0 * std::sqrt(load) + 32.0);
+        Q = (int)(load + 10.0 * std::sqrt(load));
     }
     Q = ((Q + 63) / 64) * 64;
+    if (Q < 64) Q = 64;
     if (Q > 4096) { orlg_destroy(e); return fail(ORLG_ERR_INVALID, "queue_capacity %d too large for LDS (max 4096)", Q); }
     p.Q = Q;
 
@@ -349,6 +354,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     p.l_lint = off; off = up16(off + E * 4);
     p.l_scratch = off; off = up16(off + 64 * 16);
     p.l_wsc = off; off = up16(off + (int)sizeof(OrlgWaveScalars));
+    p.l_ring = off; off = up16(off + ORLG_RING * (8 + 8 + 4));
     p.l_wave_bytes = off;
 
     int rc = ORLG_OK;
@@ -393,13 +399,6 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         p.t_brcum = put(c->bit_rate_cum, (size_t)NBR * 8);
         p.t_srccum = put(c->src_cum, (size_t)N * 8);
         p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
-        // exact quotient tables for _update_link_stats: k / S (rmsa_env.py:567-574) and 1 / u (:620-622)
-        std::vector<double> util(S + 1), inv(S + 2);
-        for (int k = 0; k <= S; k++) util[k] = (double)k / (double)S;
-        inv[0] = 0.0;
-        for (int u = 1; u < S + 2; u++) inv[u] = 1.0 / (double)u;
-        p.t_util = put(util.data(), util.size() * 8);
-        p.t_inv = put(inv.data(), inv.size() * 8);
         p.tab_bytes = (int32_t)blob.size();
         p.l_outs = p.tab_bytes;
         p.l_shared_bytes = p.tab_bytes + up16(ORLG_NUM_OUTS * 8);
@@ -408,9 +407,18 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     // environments (waves) per workgroup: as many as fit in the 160 KiB of LDS next to the staged tables, so
     // that two workgroups still fit on a CU when possible
     {
-        int wpb = ORLG_MAX_WAVES_PER_BLOCK;
-        while (wpb > 1 && (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 80 * 1024) wpb >>= 1;
-        if ((size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes > 160 * 1024) {
+        // pick the workgroup size that keeps the most environments (waves) resident per CU: 160 KiB of LDS, at most
+        // 16 waves per CU wanted (4 per SIMD, the kernel's register budget); ties go to the larger workgroup
+        const size_t lds_cu = 160 * 1024;
+        int wpb = 0, best_waves = 0;
+        for (int cand = ORLG_MAX_WAVES_PER_BLOCK; cand >= 1; cand >>= 1) {
+            size_t blk = (size_t)p.l_shared_bytes + (size_t)cand * p.l_wave_bytes;
+            if (blk > lds_cu) continue;
+            int waves = (int)(lds_cu / blk) * cand;
+            if (waves > 16) waves = 16;
+            if (waves > best_waves) { best_waves = waves; wpb = cand; }
+        }
+        if (wpb == 0) {
             size_t need = (size_t)p.l_shared_bytes + (size_t)p.l_wave_bytes;
             orlg_destroy(e);
             return fail(ORLG_ERR_INVALID, "tables + one environment (%zu B) exceed the 160 KiB LDS", need);
@@ -426,6 +434,9 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     TRY(dev_alloc(e, &p.scal, (size_t)batch));
     TRY(dev_alloc(e, &p.hist, (size_t)batch * 4 * NBR));
     TRY(dev_alloc(e, &p.lstat, (size_t)batch * 4 * E));
+    TRY(dev_alloc(e, &p.ring_iat, (size_t)batch * ORLG_RING));
+    TRY(dev_alloc(e, &p.ring_ht, (size_t)batch * ORLG_RING));
+    TRY(dev_alloc(e, &p.ring_req, (size_t)batch * ORLG_RING));
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
         for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
@@ -442,6 +453,21 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     }
 #undef TRY
     *out = e;
+    return ORLG_OK;
+}
+
+/* launch geometry of the step kernel: out[0] waves (envs) per workgroup, out[1] LDS bytes per workgroup,
+ * out[2] workgroups resident per CU according to hipOccupancyMaxActiveBlocksPerMultiprocessor, out[3] W */
+int orlg_launch_info(orlg_env *e, int32_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    rmsa_kernel_t k = pick_rmsa(e->W, e->p.stats_level);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)e->lds_block_bytes));
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * e->waves_per_block,
+                                                         e->lds_block_bytes));
+    out[0] = e->waves_per_block; out[1] = (int32_t)e->lds_block_bytes; out[2] = nb; out[3] = e->W;
     return ORLG_OK;
 }
 

@@ -11,6 +11,7 @@
 #define ORLG_MAX_HOPS 14
 #define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
 #define ORLG_NUM_OUTS 12
+#define ORLG_RING 64           // arrivals generated per refill (one per lane)
 
 // One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
 // "index" of every hop (utils.py:27-36, rmsa_env.py:479-483).
@@ -33,7 +34,8 @@ struct __attribute__((aligned(16))) OrlgEnvScalars {
     int32_t mt_idx;                                        // MT19937 position (0..624)
     int32_t new_service;                                   // self._new_service
     int32_t q_overflow;                                    // release queue overflowed (error)
-    int32_t pad[5];
+    int32_t ring_pos, ring_cnt;                            // pre-generated arrivals: next entry, entries left
+    int32_t pad[3];
 };
 static_assert(sizeof(OrlgEnvScalars) == 192, "OrlgEnvScalars layout");
 
@@ -72,6 +74,8 @@ struct OrlgParams {
     OrlgEnvScalars *scal;     // [B]
     int32_t *hist;            // [B][4][NBR] requested, provisioned, episode requested, episode provisioned
     double *lstat;            // [B][4][E] utilization, external_fragmentation, compactness, last_update
+    double *ring_iat, *ring_ht;   // [B][64] pre-generated inter-arrival / holding times (in RNG stream order)
+    uint32_t *ring_req;           // [B][64] src | dst << 8 | bit-rate index << 16
     // read-only tables: ONE blob in HBM that every workgroup stages into LDS (byte offsets t_*, 16-B aligned)
     const unsigned char *tables;
     int32_t tab_bytes;
@@ -82,14 +86,12 @@ struct OrlgParams {
     int32_t t_brcum;          // double [NBR]
     int32_t t_srccum;         // double [N]
     int32_t t_dstcum;         // double [N*N]
-    int32_t t_util;           // double [S+1]        k / S
-    int32_t t_inv;            // double [S+2]        1 / u
     // per-call IO
     const int32_t *actions;
     void *outs[ORLG_NUM_OUTS];
     double *o_obs;
     // per-wave LDS layout (byte offsets from the wave's base) and size
-    int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_wave_bytes;
+    int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_ring, l_wave_bytes;
     int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions
     int32_t l_outs;           // byte offset of the staged outs[] array
 };

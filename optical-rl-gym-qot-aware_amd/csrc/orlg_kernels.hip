@@ -100,7 +100,7 @@ struct Tab {  // topology tables staged in LDS (shared by the waves of a workgro
     const OrlgPathRec *recs;
     const uint16_t *nslots;
     const int32_t *bit_rates;
-    const double *br_cum, *src_cum, *dst_cum, *util_tab, *inv_tab;
+    const double *br_cum, *src_cum, *dst_cum;
     const u64 *outs;
 };
 
@@ -115,6 +115,8 @@ struct Wave {  // this wave's environment in LDS
     int32_t *lint; // [E] span | gaps << 16
     uint32_t *scratch;
     OrlgWaveScalars *wsc;
+    double *ring_iat, *ring_ht;  // [ORLG_RING] pre-generated arrivals
+    uint32_t *ring_req;          // [ORLG_RING]
 };
 
 DEV Tab make_tab(unsigned char *smem, const OrlgParams &p) {
@@ -126,8 +128,6 @@ DEV Tab make_tab(unsigned char *smem, const OrlgParams &p) {
     tb.br_cum = reinterpret_cast<const double *>(smem + p.t_brcum);
     tb.src_cum = reinterpret_cast<const double *>(smem + p.t_srccum);
     tb.dst_cum = reinterpret_cast<const double *>(smem + p.t_dstcum);
-    tb.util_tab = reinterpret_cast<const double *>(smem + p.t_util);
-    tb.inv_tab = reinterpret_cast<const double *>(smem + p.t_inv);
     tb.outs = reinterpret_cast<const u64 *>(smem + p.l_outs);
     return tb;
 }
@@ -195,6 +195,68 @@ DEV int choice_cum(const double *cum, int n, double u, int lane) {
     double x = u * total;
     double c = lane < n - 1 ? cum[lane] : 0.0;
     return popc64(ballot(lane < n - 1 && c <= x));
+}
+
+// Pre-generate arrivals, one per lane (_next_service's five random() draws each: inter-arrival, holding time, source,
+// destination, bit rate -- rmsa_env.py:646-659, optical_network_env.py:197-206).  The arrival process does not depend
+// on the network state, so lane j produces request j of the RNG stream: words [idx + 10 j, idx + 10 j + 10).  At most
+// one MT19937 regeneration happens inside a refill (n is capped accordingly), exactly where the sequential
+// generator would do it.  Returns the number of requests written to the ring.
+__device__ __noinline__ int refill_requests(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req,
+                                            const double *src_cum, const double *dst_cum, const double *br_cum, int *idx_io,
+                                            int N, int NBR, double lam_arrival, double lam_holding) {
+    // out of line on purpose: it runs once per ~62 steps and must not add register pressure to the step loop
+    const int lane = threadIdx.x & 63;
+    int idx = *idx_io;
+    const double ylam_arrival = recip_refine(lam_arrival), ylam_holding = recip_refine(lam_holding);
+    int n = (2 * ORLG_MT_N - idx) / 10;
+    n = n > ORLG_RING ? ORLG_RING : n;
+    uint32_t w[10];
+    const int g0 = idx + 10 * lane;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = (lane < n && g0 + k < ORLG_MT_N) ? mt[g0 + k] : 0u;
+    if (idx + 10 * n > ORLG_MT_N) {
+        mt_regenerate(mt, lane);
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+            if (lane < n && g0 + k >= ORLG_MT_N) w[k] = mt[g0 + k - ORLG_MT_N];
+        idx = idx + 10 * n - ORLG_MT_N;
+    } else {
+        idx += 10 * n;
+    }
+    double u[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        uint32_t a = w[2 * q], b = w[2 * q + 1];
+        a ^= (a >> 11); a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= (a >> 18);
+        b ^= (b >> 11); b ^= (b << 7) & 0x9d2c5680u; b ^= (b << 15) & 0xefc60000u; b ^= (b >> 18);
+        u[q] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    const double iat = div_by(-orlg_log(1.0 - u[0]), lam_arrival, ylam_arrival);
+    const double ht = div_by(-orlg_log(1.0 - u[1]), lam_holding, ylam_holding);
+    // random.choices: bisect_right(cum, u * total, 0, n - 1) = #{i < n - 1 : cum[i] <= x}
+    int src = 0, dst = 0, bri = 0;
+    {
+        const double x = u[2] * (src_cum[N - 1] + 0.0);
+        for (int i = 0; i < N - 1; ++i) src += src_cum[i] <= x ? 1 : 0;
+    }
+    {
+        const double *row = dst_cum + src * N;
+        const double x = u[3] * (row[N - 1] + 0.0);
+        for (int i = 0; i < N - 1; ++i) dst += row[i] <= x ? 1 : 0;
+    }
+    {
+        const double x = u[4] * (br_cum[NBR - 1] + 0.0);
+        for (int i = 0; i < NBR - 1; ++i) bri += br_cum[i] <= x ? 1 : 0;
+    }
+    if (lane < n) {
+        ring_iat[lane] = iat;
+        ring_ht[lane] = ht;
+        ring_req[lane] = (uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)bri << 16);
+    }
+    wave_sync();
+    *idx_io = idx;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------- first fit
@@ -322,7 +384,8 @@ DEV double np_mean(const double *a, int n) {  // n <= 512: at most two levels of
 
 // _get_network_compactness (rmsa_env.py:844-851) from the maintained integer sums
 DEV double network_compactness(int sum_span, int sum_slots_hops, int sum_gaps, int E) {
-    if (sum_gaps > 0) return ((double)sum_span / (double)sum_slots_hops) * ((double)E / (double)sum_gaps);
+    if (sum_gaps > 0)
+        return ORLG_FDIV((double)sum_span, (double)sum_slots_hops) * ORLG_FDIV((double)E, (double)sum_gaps);
     return 1.0;
 }
 
@@ -436,11 +499,11 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                     const u64 *row = wv.occ + link * W;
                     bool first_free = row[0] & 1ull;
                     bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
-                    cur0 = tb.util_tab[S - freec];  // (S - free) / S
+                    cur0 = ORLG_FDIV((double)(S - freec), (double)S);
                     if (freec > 0) {
                         int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
-                        cur1 = 1.0 - ((double)max_empty / (double)freec);
-                        cur2 = U > 1 ? ((double)(lmax - lmin) / (double)(S - freec)) * tb.inv_tab[U] : 1.0;
+                        cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
+                        cur2 = U > 1 ? ORLG_FDIV((double)(lmax - lmin), (double)(S - freec)) * ORLG_FDIV(1.0, (double)U) : 1.0;
                     }
                 } else {
                     last_update = wv.wsc->g_lu;
@@ -505,6 +568,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     wv.lint = reinterpret_cast<int32_t *>(wb + p.l_lint);
     wv.scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);
     wv.wsc = reinterpret_cast<OrlgWaveScalars *>(wb + p.l_wsc);
+    wv.ring_iat = reinterpret_cast<double *>(wb + p.l_ring);
+    wv.ring_ht = wv.ring_iat + ORLG_RING;
+    wv.ring_req = reinterpret_cast<uint32_t *>(wv.ring_ht + ORLG_RING);
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     constexpr bool NET = STATS >= 1;
@@ -526,6 +592,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
         const int32_t *gh = p.hist + (size_t)env * 4 * NBR;
         for (int i = lane; i < 4 * NBR; i += 64) wv.hist[i] = gh[i];
         for (int i = lane; i < E; i += 64) wv.lint[i] = 0;
+        wv.ring_iat[lane] = p.ring_iat[(size_t)env * ORLG_RING + lane];
+        wv.ring_ht[lane] = p.ring_ht[(size_t)env * ORLG_RING + lane];
+        wv.ring_req[lane] = p.ring_req[(size_t)env * ORLG_RING + lane];
     }
     const OrlgEnvScalars *gs = p.scal + env;
     if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
@@ -543,8 +612,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     int sum_sh = gs->sum_slots_hops;
     int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
+    int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
     int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     wave_sync();
+
 
     int sum_span = 0, sum_gaps = 0;
     if (NET) {
@@ -711,18 +782,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
 
         // ============================================================== _next_service (rmsa_env.py:643-695)
         if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
-            double u[5];
-            draw5(wv, mt_idx, u);
-            // expovariate: -log(1 - u) / lambd ; lane 0 does the inter-arrival, lane 2 the holding time
-            double uu = lane == 2 ? u[1] : u[0];
-            double lam = lane == 2 ? p.holding_lambda : p.arrival_lambda;
-            double ex = -orlg_log(1.0 - uu) / lam;
-            double at = current_time + readlane_d(ex, 0);
-            double ht = readlane_d(ex, 2);
+            if (ring_cnt == 0) {
+                ring_cnt = refill_requests(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
+                                           &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda);
+                ring_pos = 0;
+            }
+            const double at = current_time + wv.ring_iat[ring_pos];
+            const double ht = wv.ring_ht[ring_pos];
+            const uint32_t rq = wv.ring_req[ring_pos];
+            ring_pos += 1; ring_cnt -= 1;
             current_time = at;
-            int src = choice_cum(tb.src_cum, N, u[2], lane);
-            int dst = choice_cum(tb.dst_cum + src * N, N, u[3], lane);
-            int bri = choice_cum(tb.br_cum, NBR, u[4], lane);
+            const int src = (int)(rq & 0xffu), dst = (int)((rq >> 8) & 0xffu), bri = (int)(rq >> 16);
             req_sid = eproc;
             req_src = src; req_dst = dst; req_br = bri;
             new_service = 1;
@@ -810,6 +880,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
         }
         int32_t *gh = kp->hist + (size_t)env * 4 * NBR;
         for (int i = lane; i < 4 * NBR; i += 64) gh[i] = wv.hist[i];
+        kp->ring_iat[(size_t)env * ORLG_RING + lane] = wv.ring_iat[lane];
+        kp->ring_ht[(size_t)env * ORLG_RING + lane] = wv.ring_ht[lane];
+        kp->ring_req[(size_t)env * ORLG_RING + lane] = wv.ring_req[lane];
         OrlgEnvScalars *go = kp->scal + env;
         const OrlgWaveScalars *ws = wv.wsc;
         if (lane < 8) go->c[lane] = ws->c[lane];
@@ -822,6 +895,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             go->sum_slots_hops = sum_sh; go->n_running = ws->n_running;
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
+            go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
         }
     }
 }

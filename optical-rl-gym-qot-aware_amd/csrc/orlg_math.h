@@ -27,6 +27,25 @@ ORLG_HD double orlg_u2d(uint64_t u) {
     return c.d;
 }
 
+// a / b: on the device the gfx9 fdiv-f64 expansion without v_div_scale / v_div_fixup (identities for the normal-range
+// operands used here), i.e. the same correctly rounded quotient as the host's IEEE division, in 8 instead of ~14
+// instructions.  Host/device agreement is asserted by the GPU parity tests (every float bit-exact vs the oracle).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline double orlg_fdiv(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+#define ORLG_FDIV(a, b) orlg_fdiv((a), (b))
+#else
+#define ORLG_FDIV(a, b) ((a) / (b))
+#endif
+
 ORLG_HD double orlg_log(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -60,7 +79,7 @@ ORLG_HD double orlg_log(double x) {
         if (k == 0) return f - R;
         return dk * ln2_hi - ((R - dk * ln2_lo) - f);
     }
-    double s = f / (2.0 + f);
+    double s = ORLG_FDIV(f, 2.0 + f);
     double z = s * s;
     i = hx - 0x6147a;
     double w = z * z;

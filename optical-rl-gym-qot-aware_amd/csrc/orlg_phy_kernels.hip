@@ -439,7 +439,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             draw5(wv, mt_idx, u);
             double uu = lane == 2 ? u[1] : u[0];
             double lam = lane == 2 ? p.holding_lambda : p.arrival_lambda;
-            double ex = -orlg_log(1.0 - uu) / lam;
+            double ex = div_by(-orlg_log(1.0 - uu), lam, recip_refine(lam));
             double at = current_time + readlane_d(ex, 0);
             double ht = readlane_d(ex, 2);
             current_time = at;
