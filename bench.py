@@ -139,6 +139,15 @@ def main():
         n_per_launch = full[0][1]
         A = algorithmic_bytes_per_env_step(topo, W)
         achieved = A * B * n_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch measured with rocprofv3 PMC passes on this workload (profiles/traffic.json), if recorded
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]
+            ent = tj.get(f"rmsa_nsfnet320_B{B}_chunk{n_per_launch}_{args.stats}_{args.policy}")
+            if ent:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
+        except Exception:
+            pass
         out = {
             "metric": "env steps/sec (whole node) + blocking-prob parity, NSFNET RMSA 320 slots",
             "value": total_steps / elapsed,
@@ -157,7 +166,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "policy": args.policy, "stats_level": args.stats,
                        "chunk": args.chunk, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "orlg_rmsa_kernel<5,%d>" % {"counters": 0, "network": 1, "full": 2}[args.stats],
                          "kernel_ms_per_launch": avg_ms, "algorithmic_bytes_per_env_step": A,
                          "env_steps_per_launch": B * n_per_launch},
