@@ -206,6 +206,7 @@ typedef struct orlg_phy_config {
 enum {
     ORLG_PHY_POLICY_EXTERNAL = -1, /* caller supplies (path, channels) per env */
     ORLG_PHY_POLICY_BMFA_CUT = 0,  /* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438), grooming off */
+    ORLG_PHY_POLICY_BMFA_RSS_METRIC = 1, /* phy_aware_bmfa_rss_rmsa (phy_rmsa_env.py:1441-1505), grooming off */
 };
 #define ORLG_PHY_MAX_CHANNELS 14 /* channels per service */
 

@@ -66,7 +66,7 @@ PHY_MAX_CHANNELS = 14
 PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
                       "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
                       "number_cuts_total": "float64", "rss_total_metric": "float64"}
-PHY_POLICIES = {"external": -1, "bmfa": 0}
+PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1}
 
 _lib = None
 

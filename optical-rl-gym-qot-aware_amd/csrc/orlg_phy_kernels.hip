@@ -37,7 +37,7 @@ struct __attribute__((aligned(16))) OrlgPhyScalars {
 };
 static_assert(sizeof(OrlgPhyScalars) == 224, "OrlgPhyScalars layout");
 
-enum { ORLG_PHY_POLICY_EXT = -1, ORLG_PHY_POLICY_BMFA = 0 };
+enum { ORLG_PHY_POLICY_EXT = -1, ORLG_PHY_POLICY_BMFA = 0, ORLG_PHY_POLICY_BMFA_RSS = 1 };
 enum { ORLG_PHY_OUT_PATH = 0, ORLG_PHY_OUT_NCH, ORLG_PHY_OUT_CHANNELS, ORLG_PHY_OUT_ACCEPTED, ORLG_PHY_OUT_DONE,
        ORLG_PHY_OUT_REQUEST, ORLG_PHY_OUT_ARRIVAL, ORLG_PHY_OUT_HOLDING, ORLG_PHY_OUT_CUTS, ORLG_PHY_OUT_RSS,
        ORLG_PHY_NUM_OUTS };
@@ -147,6 +147,92 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
     (void)want_cuts;
 }
 
+// Level and fragmentation metric of the lane's channel in every word of candidate path `idp` (level -1: not free).
+//   cut (calculate_r_cut modified, phy_rmsa_env.py:1140-1193): for a channel free on the path the "cuts before minus
+//   cuts after" against the links adjacent to the path's nodes reduce to  sum_j weight_j * (1 - 2 * available[link_j]);
+//   rss (calculate_r_spatial, :1085-1108): sqrt(sum len^2) / (sum len + 1) over the free runs of the channel's column
+//   along the link axis, after taking the channel on the path's links minus before.
+template <int W>
+DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, int row, int lane,
+                         bool rss, int (&lv)[W], double (&mt)[W]) {
+    const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
+    const uint8_t *mrow = p.mod_t + (size_t)(row * p.K + idp) * p.cpad;
+    // links of the path as a bit set (E <= 255: four words)
+    const OrlgPathRec *rec = tb.recs + gid;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const u64 x = readlane64(acc, idp * W + w);
+        lv[w] = -1; mt[w] = 0.0;
+        if (x != 0ull) {
+            const int ch = 64 * w + lane;
+            const bool fr = ((x >> lane) & 1ull) && ch < p.C;
+            const int level = (int)mrow[ch];
+            double metric;
+            if (!rss) {
+                int m = 0;
+                for (int j = a0; j < a1; ++j) {
+                    const unsigned aw = tb.adj[j];
+                    const int link = (int)(aw & 0xffu), wt = (int)(aw >> 8);
+                    const int b = (int)((occ[__mul24(link, W) + w] >> lane) & 1ull);
+                    m += wt * (1 - 2 * b);
+                }
+                metric = (double)m;
+            } else {
+                int cur0 = 0, sq0 = 0, sm0 = 0, cur1 = 0, sq1 = 0, sm1 = 0;
+                u64 pm[4] = {0ull, 0ull, 0ull, 0ull};  // the path's links as a bit set (wave-uniform)
+                for (int h = 0; h < rec->hops; ++h) {
+                    const int pl = (int)rec->link[h];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((pl >> 6) == q) pm[q] |= 1ull << (pl & 63);
+                }
+                for (int l = 0; l < p.E; ++l) {
+                    const int b = (int)((occ[__mul24(l, W) + w] >> lane) & 1ull);
+                    const u64 pw = (l >> 6) == 0 ? pm[0] : (l >> 6) == 1 ? pm[1] : (l >> 6) == 2 ? pm[2] : pm[3];
+                    const bool on_path = (pw >> (l & 63)) & 1ull;
+                    const int b1 = on_path ? 0 : b;
+                    if (b) { cur0 += 1; } else { sq0 += cur0 * cur0; sm0 += cur0; cur0 = 0; }
+                    if (b1) { cur1 += 1; } else { sq1 += cur1 * cur1; sm1 += cur1; cur1 = 0; }
+                }
+                sq0 += cur0 * cur0; sm0 += cur0; sq1 += cur1 * cur1; sm1 += cur1;
+                const double r0 = ORLG_FDIV(tb.sqrt_tab[sq0], (double)(sm0 + 1));
+                const double r1 = ORLG_FDIV(tb.sqrt_tab[sq1], (double)(sm1 + 1));
+                metric = r1 - r0;
+            }
+            if (fr) { lv[w] = level; mt[w] = metric; }
+        }
+    }
+}
+
+// Best remaining channel of a row in sorted order: max level, then max metric, then min channel (wave-wide).
+template <int W>
+DEV void phy_row_best(const int (&lv)[W], const double (&mt)[W], int lane, int &level, double &metric, int &channel) {
+    int L = -1;
+#pragma unroll
+    for (int w = 0; w < W; ++w) L = lv[w] > L ? lv[w] : L;
+    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(L, off); L = o > L ? o : L; }
+    L = uni(L);
+    level = L; metric = 0.0; channel = -1;
+    if (L < 0) return;
+    bool have = false;
+    double M = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+        if (lv[w] == L && (!have || mt[w] > M)) { M = mt[w]; have = true; }
+    for (int off = 32; off > 0; off >>= 1) {
+        double om = __shfl_xor(M, off);
+        int oh = __shfl_xor((int)have, off);
+        if (oh && (!have || om > M)) { M = om; have = true; }
+    }
+    M = readlane_d(M, 0);
+    int Cc = 0x7fffffff;
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+        if (lv[w] == L && mt[w] == M) { int c = 64 * w + lane; Cc = c < Cc ? c : Cc; }
+    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(Cc, off); Cc = o < Cc ? o : Cc; }
+    metric = M; channel = uni(Cc);
+}
+
 template <int W>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -234,105 +320,59 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                 }
                 wave_sync();
             } else {
-                // ---------------- phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438), grooming off
-                // (path, word) lanes: path-wide free bitmaps
+                // ---------------- phy_aware_bmfa_rmsa / phy_aware_bmfa_rss_rmsa (phy_rmsa_env.py:1375-1505), grooming off.
+                // Per path ("row") the free channels are ordered by (level desc, fragmentation metric desc, channel asc)
+                // = sorted(row, key=(-level, -metric)); the row with the best head (level, metric) is tried first,
+                // its channels are taken in order until the bit rate is covered, otherwise the row is dropped.
+                const bool rss = p.policy == ORLG_PHY_POLICY_BMFA_RSS;
                 const int pp = lane / W, pw = lane - pp * W;
-                u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-                // per (path, word): score of lane's channel = level << 18 | (cut metric + 128) << 10 | (1023 - channel)
-                // (larger = earlier in sorted(row, key=(-level, -metric)); ties keep channel order)
-                unsigned score[ORLG_PHY_MAX_K][W];
-                unsigned alive = 0;  // bit idp set: row still usable
+                const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
+                // pass 1: head (level, metric) of every row
+                int head_level[ORLG_PHY_MAX_K];
+                double head_metric[ORLG_PHY_MAX_K];
+                unsigned alive = 0;
 #pragma unroll
                 for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
-#pragma unroll
-                    for (int w = 0; w < W; ++w) score[idp][w] = 0u;
-                }
-#pragma unroll
-                for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
+                    head_level[idp] = -1; head_metric[idp] = 0.0;
                     if (idp < K) {
-                        const int gid = base + idp;
-                        const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
-                        const uint8_t *mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
-                        bool any = false;
-#pragma unroll
-                        for (int w = 0; w < W; ++w) {
-                            const u64 x = readlane64(acc, idp * W + w);
-                            if (x != 0ull) {
-                                const int ch = 64 * w + lane;
-                                const bool fr = (x >> lane) & 1ull;
-                                const int level = (int)mrow[ch];
-                                // calculate_r_cut(modified): sum_j weight_j * (1 - 2 * available[link_j][ch])
-                                int metric = 0;
-                                for (int j = a0; j < a1; ++j) {
-                                    const unsigned aw = tb.adj[j];
-                                    const int link = (int)(aw & 0xffu), wt = (int)(aw >> 8);
-                                    const int b = (int)((occ[__mul24(link, W) + w] >> lane) & 1ull);
-                                    metric += wt * (1 - 2 * b);
-                                }
-                                const unsigned sc =
-                                    ((unsigned)level << 18) | ((unsigned)(metric + 128) << 10) | (unsigned)(1023 - ch);
-                                score[idp][w] = (fr && ch < C) ? sc : 0u;
-                                any = true;
-                            }
-                        }
-                        if (any) alive |= 1u << idp;
+                        int lv[W];
+                        double mt[W];
+                        phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, row, lane, rss, lv, mt);
+                        int bl; double bm; int bc;
+                        phy_row_best<W>(lv, mt, lane, bl, bm, bc);
+                        if (bl >= 0) { head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp; }
                     }
                 }
-                // greedy row selection
                 for (;;) {
-                    unsigned best_head = 0;
-                    int best = -1;
-#pragma unroll
-                    for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
-                        if (idp < K && ((alive >> idp) & 1u)) {
-                            unsigned m = 0;
-#pragma unroll
-                            for (int w = 0; w < W; ++w) m = score[idp][w] > m ? score[idp][w] : m;
-                            for (int off = 32; off > 0; off >>= 1) {
-                                unsigned o = (unsigned)__shfl_xor((int)m, off);
-                                m = o > m ? o : m;
-                            }
-                            m = (unsigned)uni((int)m);
-                            if (m == 0u) {
-                                alive &= ~(1u << idp);
-                            } else if (best < 0 || (m >> 10) > (best_head >> 10)) {
-                                // row[0][0] > max_level or (== and row[0][1] > max_metric): (level, metric) only
-                                best_head = m; best = idp;
-                            }
-                        }
-                    }
-                    if (best < 0) break;
-                    // the chosen row, selected with compile-time indices
-                    unsigned cur[W];
-#pragma unroll
-                    for (int w = 0; w < W; ++w) cur[w] = 0u;
+                    int best = -1, bl = -1;
+                    double bm = 0.0;
 #pragma unroll
                     for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
-                        if (idp == best) {
-#pragma unroll
-                            for (int w = 0; w < W; ++w) cur[w] = score[idp][w];
+                        if (idp < K && ((alive >> idp) & 1u)) {
+                            // row[0][0] > max_level or (row[0][0] == max_level and row[0][1] > max_metric)
+                            if (best < 0 || head_level[idp] > bl || (head_level[idp] == bl && head_metric[idp] > bm)) {
+                                best = idp; bl = head_level[idp]; bm = head_metric[idp];
+                            }
                         }
-                    // take its channels in sorted order until the demand is covered
+                    if (best < 0) break;
+                    // pass 2: the chosen row again, then greedy extraction in sorted order
+                    int lv[W];
+                    double mt[W];
+                    phy_row_metrics<W>(occ, tb, p, acc, best, base + best, row, lane, rss, lv, mt);
                     int unassigned = demand;
                     nsel = 0;
                     bool covered = false;
                     while (nsel < ORLG_PHY_MAX_CH) {
-                        unsigned m = 0;
-#pragma unroll
-                        for (int w = 0; w < W; ++w) m = cur[w] > m ? cur[w] : m;
-                        for (int off = 32; off > 0; off >>= 1) {
-                            unsigned o = (unsigned)__shfl_xor((int)m, off);
-                            m = o > m ? o : m;
-                        }
-                        m = (unsigned)uni((int)m);
-                        if (m == 0u) break;
-                        const int ch = 1023 - (int)(m & 0x3ffu), level = (int)(m >> 18);
+                        int l0, c0;
+                        double m0;
+                        phy_row_best<W>(lv, mt, lane, l0, m0, c0);
+                        if (l0 < 0) break;
 #pragma unroll
                         for (int w = 0; w < W; ++w)
-                            if (cur[w] == m) cur[w] = 0u;
-                        if (lane == 0) { sel_ch[nsel] = ch; sel_mod[nsel] = level; }
+                            if (64 * w + lane == c0) lv[w] = -1;
+                        if (lane == 0) { sel_ch[nsel] = c0; sel_mod[nsel] = l0; }
                         nsel += 1;
-                        unassigned -= level * 100;
+                        unassigned -= l0 * 100;
                         if (unassigned <= 0) { covered = true; break; }
                     }
                     if (covered) { a_path = best; break; }

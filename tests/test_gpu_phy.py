@@ -20,7 +20,7 @@ def make_env(topo, tables, kw, batch, **extra):
 
 
 @pytest.mark.parametrize("case,nmax", [("phy_us14_s10_bmfa", 800), ("phy_jpn12_s3_bmfa", 500),
-                                       ("phy_us14_s12_bmfa_load4000", 2600)])
+                                       ("phy_us14_s12_bmfa_load4000", 2600), ("phy_us14_s10_bmfa_rss", 600)])
 def test_phy_bmfa_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     z, meta = load_golden(case)
     topo = load_topology(meta["topology"])
@@ -28,11 +28,12 @@ def test_phy_bmfa_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     kw = meta["env_kwargs"]
     n, batch = min(nmax, meta["steps"]), 4
     env = make_env(topo, tables, kw, batch)
-    tr = env.run("bmfa", n, outputs=OUTS, auto_reset=True)
+    policy = meta["policy"]
+    tr = env.run(policy, n, outputs=OUTS, auto_reset=True)
     cnt, now, nrun, av, est = env.counters(), env.current_time(), env.num_running(), env.available_channels(), env.episode_stats()
     for i in range(batch):
         o = phy_oracle_from_kwargs(topo, tables, kw, seed=kw["seed"] + i)
-        ot = o.run("bmfa", n, reset_on_done=True)
+        ot = o.run(policy, n, reset_on_done=True)
         assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
         assert np.array_equal(tr["n_channels"][:, i], ot["n_channels"]), i
         assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
