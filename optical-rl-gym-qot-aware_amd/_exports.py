@@ -4,13 +4,14 @@ from .batched import DEFAULT_BIT_RATES, BatchedDeepRMSAEnv, BatchedRMSAEnv
 from .envs import (DeepRMSAEnv, RMSAEnv, deeprmsa_shortest_available_path_first_fit,
                    deeprmsa_shortest_path_first_fit, evaluate_heuristic, least_loaded_path_first_fit,
                    random_policy, shortest_available_path_first_fit, shortest_path_first_fit)
+from .monitor import evaluate_heuristic_batched, write_monitor_csv
 from .osnr import gn_osnr, modulation_level_from_gsnr
 from .phy import BatchedPhyRMSAEnv
 from .phy_env import PhyRMSAEnv, phy_aware_bmfa_rmsa
 from .topology import FrozenTopology, Modulation, Path, Service, TopologyView, selection_tables
 
 __all__ = ["FrozenTopology", "Modulation", "Path", "Service", "TopologyView", "selection_tables",
-           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "BatchedPhyRMSAEnv", "PhyRMSAEnv", "phy_aware_bmfa_rmsa", "gn_osnr", "modulation_level_from_gsnr", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
+           "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "BatchedPhyRMSAEnv", "PhyRMSAEnv", "phy_aware_bmfa_rmsa", "gn_osnr", "evaluate_heuristic_batched", "write_monitor_csv", "modulation_level_from_gsnr", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
            "RMSAEnv", "DeepRMSAEnv", "shortest_path_first_fit", "shortest_available_path_first_fit",
            "least_loaded_path_first_fit", "deeprmsa_shortest_path_first_fit",
            "deeprmsa_shortest_available_path_first_fit", "random_policy", "evaluate_heuristic"]
