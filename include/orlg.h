@@ -85,7 +85,9 @@ enum {
     ORLG_POLICY_LLP_FF = 2,           /* least_loaded_path_first_fit */
     ORLG_POLICY_DEEPRMSA_SP_FF = 3,   /* deeprmsa_env.shortest_path_first_fit (allow_rejection=False) */
     ORLG_POLICY_DEEPRMSA_SAP_FF = 4,  /* deeprmsa_env.shortest_available_path_first_fit */
-    ORLG_POLICY_DEEPRMSA_EXTERNAL = 5 /* caller supplies Discrete(k*j) actions (deeprmsa_env.py:48-58) */
+    ORLG_POLICY_DEEPRMSA_EXTERNAL = 5, /* caller supplies Discrete(k*j) actions (deeprmsa_env.py:48-58) */
+    ORLG_POLICY_PATH_FF_EXTERNAL = 6   /* caller supplies the path, first fit the slot: PathOnlyFirstFitAction
+                                          (rmsa_env.py:974-1008); actions is [B] int32 */
 };
 
 /* Optional per-step outputs of orlg_step(); any pointer may be NULL.  Arrays are [n_steps][B]
@@ -174,6 +176,10 @@ int orlg_query_path_mask(orlg_env *env, int32_t env_index, int32_t path_gid, uin
 /* DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env: [B][1 + 2N + (2j+3)k] float64 */
 int orlg_deeprmsa_observation(orlg_env *env, double *out);
 int orlg_deeprmsa_obs_dim(orlg_env *env);
+
+/* SimpleMatrixObservation.observation() (rmsa_env.py:940-971) for every env: [B][2N + E*S] uint8 */
+int orlg_simple_matrix_observation(orlg_env *env, uint8_t *out);
+int orlg_simple_matrix_obs_dim(orlg_env *env);
 
 /* sum of all B counter records + accepted/processed, for multi-GPU statistics: out[0..7] = orlg_counters summed,
  * out[8] = total episodes done, out[9] = B.  The caller all-reduces this vector (RCCL, SUM). */

@@ -1,7 +1,7 @@
 from . import _lib, envs
 from ._lib import OrlgError
 from .batched import DEFAULT_BIT_RATES, BatchedDeepRMSAEnv, BatchedRMSAEnv
-from .envs import (DeepRMSAEnv, RMSAEnv, deeprmsa_shortest_available_path_first_fit,
+from .envs import (DeepRMSAEnv, PathOnlyFirstFitAction, RMSAEnv, SimpleMatrixObservation, deeprmsa_shortest_available_path_first_fit,
                    deeprmsa_shortest_path_first_fit, evaluate_heuristic, least_loaded_path_first_fit,
                    random_policy, shortest_available_path_first_fit, shortest_path_first_fit)
 from .monitor import evaluate_heuristic_batched, write_monitor_csv
@@ -12,6 +12,6 @@ from .topology import FrozenTopology, Modulation, Path, Service, TopologyView, s
 
 __all__ = ["FrozenTopology", "Modulation", "Path", "Service", "TopologyView", "selection_tables",
            "BatchedRMSAEnv", "BatchedDeepRMSAEnv", "BatchedPhyRMSAEnv", "PhyRMSAEnv", "phy_aware_bmfa_rmsa", "gn_osnr", "evaluate_heuristic_batched", "write_monitor_csv", "modulation_level_from_gsnr", "DEFAULT_BIT_RATES", "OrlgError", "_lib", "envs",
-           "RMSAEnv", "DeepRMSAEnv", "shortest_path_first_fit", "shortest_available_path_first_fit",
+           "RMSAEnv", "DeepRMSAEnv", "SimpleMatrixObservation", "PathOnlyFirstFitAction", "shortest_path_first_fit", "shortest_available_path_first_fit",
            "least_loaded_path_first_fit", "deeprmsa_shortest_path_first_fit",
            "deeprmsa_shortest_available_path_first_fit", "random_policy", "evaluate_heuristic"]

@@ -12,7 +12,7 @@ ERR_NAMES = {-1: "ORLG_ERR_INVALID", -2: "ORLG_ERR_NO_DEVICE", -3: "ORLG_ERR_HIP
 
 STATS_LEVELS = {"counters": 0, "network": 1, "full": 2}
 POLICIES = {"external": -1, "sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4,
-            "deeprmsa_external": 5}
+            "deeprmsa_external": 5, "path_ff_external": 6}
 
 
 class OrlgError(RuntimeError):
@@ -109,6 +109,8 @@ def load(build_if_missing=True):
     L.orlg_deeprmsa_observation.argtypes = [vp, vp]
     L.orlg_deeprmsa_obs_dim.argtypes = [vp]
     L.orlg_reduce_counters.argtypes = [vp, vp]
+    L.orlg_simple_matrix_observation.argtypes = [vp, vp]
+    L.orlg_simple_matrix_obs_dim.argtypes = [vp]
     L.orlg_phy_create.argtypes = [C.POINTER(Topology), C.POINTER(PhyConfig), i32, vp, u64, i32, C.POINTER(vp)]
     L.orlg_phy_destroy.argtypes = [vp]
     L.orlg_phy_set_stream.argtypes = [vp, vp]
@@ -132,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "orlg_get_current_time", "orlg_get_occupancy", "orlg_words_per_link", "orlg_get_link_stats",
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
     "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
-    "orlg_host_log",
+    "orlg_simple_matrix_observation", "orlg_simple_matrix_obs_dim", "orlg_host_log",
     "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",

@@ -247,6 +247,19 @@ class BatchedRMSAEnv:
         _lib.check(self.L.orlg_deeprmsa_observation(self.h, _ptr(out)))
         return out
 
+    def simple_matrix_observation(self, out=None):
+        """SimpleMatrixObservation.observation() for every env: [B, 2N + E*S] uint8 (``rmsa_env.py:940-971``)."""
+        dim = self.L.orlg_simple_matrix_obs_dim(self.h)
+        if out is None:
+            out = np.zeros((self.batch_size, dim), np.uint8)
+        _lib.check(self.L.orlg_simple_matrix_observation(self.h, _ptr(out)))
+        return out
+
+    def step_path_first_fit(self, paths, outputs=("reward", "done", "accepted")):
+        """PathOnlyFirstFitAction.step for every env: ``paths`` is [B] int32 (k = reject)."""
+        r = self.run("path_ff_external", 1, actions=paths, outputs=outputs)
+        return {k: v[0] for k, v in r.items()}
+
     def reduce_counters(self):
         """Summed counters of this shard (raises if a release queue overflowed): the vector a
         multi-GPU job all-reduces."""

@@ -514,8 +514,8 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
               const orlg_step_io *io) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     if (n_steps < 1) return fail(ORLG_ERR_INVALID, "n_steps must be >= 1");
-    if (policy < ORLG_POLICY_EXTERNAL || policy > ORLG_POLICY_DEEPRMSA_EXTERNAL) return fail(ORLG_ERR_INVALID, "unknown policy %d", policy);
-    const bool ext = policy == ORLG_POLICY_EXTERNAL || policy == ORLG_POLICY_DEEPRMSA_EXTERNAL;
+    if (policy < ORLG_POLICY_EXTERNAL || policy > ORLG_POLICY_PATH_FF_EXTERNAL) return fail(ORLG_ERR_INVALID, "unknown policy %d", policy);
+    const bool ext = policy == ORLG_POLICY_EXTERNAL || policy == ORLG_POLICY_DEEPRMSA_EXTERNAL || policy == ORLG_POLICY_PATH_FF_EXTERNAL;
     if (ext && (!actions || n_steps != 1)) return fail(ORLG_ERR_INVALID, "external actions need an action array and n_steps == 1");
     HIP_TRY(hipSetDevice(e->device));
     OrlgParams p = e->p;
@@ -705,6 +705,24 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds, e->stream, p);
+    HIP_TRY(hipGetLastError());
+    if (!dev) return copy_out(e, out, e->staging, bytes);
+    return ORLG_OK;
+}
+
+int orlg_simple_matrix_obs_dim(orlg_env *e) { return e ? 2 * e->p.N + e->p.E * e->p.S : ORLG_ERR_INVALID; }
+int orlg_simple_matrix_observation(orlg_env *e, uint8_t *out) {
+    if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->p.B * (size_t)(2 * e->p.N + e->p.E * e->p.S);
+    const bool dev = is_device_ptr(out);
+    uint8_t *d = out;
+    if (!dev) {
+        int rc = ensure_staging(e, bytes);
+        if (rc) return rc;
+        d = e->staging;
+    }
+    hipLaunchKernelGGL(orlg_simple_matrix_obs_kernel, dim3(2048), dim3(256), 0, e->stream, e->p, e->W, d);
     HIP_TRY(hipGetLastError());
     if (!dev) return copy_out(e, out, e->staging, bytes);
     return ORLG_OK;

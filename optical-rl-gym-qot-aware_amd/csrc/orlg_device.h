@@ -53,7 +53,7 @@ static_assert(sizeof(OrlgWaveScalars) == 128, "OrlgWaveScalars layout");
 enum { ORLG_MODE_STEP = 0, ORLG_MODE_INIT = 1, ORLG_MODE_EPISODE_RESET = 2 };
 // device-side policy ids (== include/orlg.h ORLG_POLICY_*)
 enum { ORLG_POLICY_EXT = -1, ORLG_POLICY_SP = 0, ORLG_POLICY_SAP = 1, ORLG_POLICY_LLP = 2, ORLG_POLICY_DEEP_SP = 3,
-       ORLG_POLICY_DEEP_SAP = 4, ORLG_POLICY_DEEP_EXT = 5 };
+       ORLG_POLICY_DEEP_SAP = 4, ORLG_POLICY_DEEP_EXT = 5, ORLG_POLICY_PATH_EXT = 6 };
 // per-step output slots (OrlgParams::outs)
 enum { ORLG_OUT_PATH = 0, ORLG_OUT_SLOT, ORLG_OUT_ACCEPTED, ORLG_OUT_DONE, ORLG_OUT_REWARD, ORLG_OUT_REQUEST,
        ORLG_OUT_ARRIVAL, ORLG_OUT_HOLDING, ORLG_OUT_COMPACT, ORLG_OUT_COMPACT_DIFF, ORLG_OUT_AVG_LINK_COMPACT,

@@ -642,6 +642,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                 const int32_t *acts = kernarg_params()->actions;
                 a_path = uni(acts[2 * env]);
                 a_slot = uni(acts[2 * env + 1]);
+            } else if (policy == ORLG_POLICY_PATH_EXT) {
+                // PathOnlyFirstFitAction.action (rmsa_env.py:982-1005): the agent picks the path, first fit picks the slot
+                int a = uni(kernarg_params()->actions[env]);
+                if (a >= 0 && a < K) {
+                    u64 x[W];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a * W + w);
+                    int n = __builtin_amdgcn_readlane(my_n, a);
+                    int s0 = first_fit<W>(x, n, S - n, lane);
+                    if (s0 >= 0) { a_path = a; a_slot = s0; }
+                }
             } else if (policy == ORLG_POLICY_DEEP_EXT) {
                 int a = uni(kernarg_params()->actions[env]);
                 if (a >= 0 && a < K * p.j) {
@@ -983,6 +994,28 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
             row[2 * J + 1] = 2 * ((double)total - 0.5 * S) / S;
             row[2 * J + 2] = runs > 0 ? ((double)total / (double)runs - 4) / 4 : -1.0;
         }
+    }
+}
+
+// SimpleMatrixObservation.observation (rmsa_env.py:952-971) for every env: [B][2N + E*S] uint8 = one-hot of the lower
+// and of the higher endpoint index, then the free-slot flags link-major (the bitmap unpacked).
+__global__ __launch_bounds__(256) void orlg_simple_matrix_obs_kernel(const OrlgParams p, int W, uint8_t *out) {
+    const size_t dim = (size_t)2 * p.N + (size_t)p.E * p.S;
+    const size_t total = dim * p.B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / dim, q = i - b * dim;
+        uint8_t v;
+        if (q < (size_t)2 * p.N) {
+            const OrlgEnvScalars *sc = p.scal + b;
+            const int mn = sc->req_src < sc->req_dst ? sc->req_src : sc->req_dst;
+            const int mx = sc->req_src < sc->req_dst ? sc->req_dst : sc->req_src;
+            v = ((int)q == mn || (int)q == p.N + mx) ? 1 : 0;
+        } else {
+            const size_t r = q - 2 * p.N;
+            const int link = (int)(r / p.S), s = (int)(r - (size_t)link * p.S);
+            v = (uint8_t)((p.occ[b * p.NW + (size_t)link * W + (s >> 6)] >> (s & 63)) & 1ull);
+        }
+        out[i] = v;
     }
 }
 

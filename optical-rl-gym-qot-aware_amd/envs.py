@@ -331,6 +331,62 @@ class DeepRMSAEnv(RMSAEnv):
         return action // self.j, action % self.j
 
 
+class SimpleMatrixObservation:
+    """``rmsa_env.py:940-971``: observation = one-hot endpoints + the E x S free-slot matrix (built on the device)."""
+
+    def __init__(self, env: RMSAEnv):
+        self.env = env
+        shape = env.topology.number_of_nodes() * 2 + env.topology.number_of_edges() * env.num_spectrum_resources
+        self.observation_space = _box(0, 1, (shape,), np.uint8)
+        self.action_space = env.action_space
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def observation(self, observation=None):
+        return self.env._batched.simple_matrix_observation()[self.env._index]
+
+    def reset(self, **kw):
+        self.env.reset(**kw)
+        return self.observation()
+
+    def step(self, action):
+        _, reward, done, info = self.env.step(action)
+        return self.observation(), reward, done, info
+
+
+class PathOnlyFirstFitAction:
+    """``rmsa_env.py:974-1008``: the agent chooses the path, the slot is the first fit (resolved on the device)."""
+
+    def __init__(self, env):
+        self.env = env
+        inner = env
+        while not isinstance(inner, RMSAEnv):
+            inner = inner.env
+        self._inner = inner
+        self.action_space = _discrete(inner.k_paths + inner.reject_action)
+        self.observation_space = getattr(env, "observation_space", None)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def action(self, action) -> Tuple[int, int]:
+        e = self._inner
+        if action < e.k_paths:
+            path = e.k_shortest_paths[e.current_service.source, e.current_service.destination][action]
+            n = e.get_number_slots(path)
+            for s in range(0, e.topology.graph["num_spectrum_resources"] - n):
+                if e.is_path_free(path, s, n):
+                    return (action, s)
+        return (e.topology.graph["k_paths"], e.topology.graph["num_spectrum_resources"])
+
+    def step(self, action):
+        return self.env.step(self.action(action))
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+
 # --------------------------------------------------------------------------------------- heuristics
 def shortest_path_first_fit(env: RMSAEnv) -> Tuple[int, int]:
     """SP-FF (``rmsa_env.py:854-871``): first fit on the shortest path only; note the exclusive bound."""

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_BIT_RATES = 64
 
 POLICY = {"sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4, "external": -1,
-          "deeprmsa_external": 5}
+          "deeprmsa_external": 5, "path_ff_external": 6}
 
 
 class Topology(C.Structure):
@@ -223,6 +223,12 @@ class OracleEnv:
     def observation(self):
         o = np.zeros(self.obs_dim)
         self.L.orc_deeprmsa_observation(self.h, _ptr(o))
+        return o
+
+    def simple_matrix_observation(self):
+        self.L.orc_simple_matrix_observation.argtypes = [C.c_void_p, C.c_void_p]
+        o = np.zeros(2 * self.N + self.E * self.S)
+        self.L.orc_simple_matrix_observation(self.h, _ptr(o))
         return o
 
     def number_slots(self, idp):

@@ -553,6 +553,15 @@ void orc_deeprmsa_observation(orc_env *e, double *out) {
     }
 }
 
+void orc_simple_matrix_observation(const orc_env *e, double *out) {
+    const service *s = e->current;
+    int mn = s->src < s->dst ? s->src : s->dst, mx = s->src < s->dst ? s->dst : s->src;
+    for (int i = 0; i < 2 * e->N; i++) out[i] = 0.0;
+    out[mn] = 1.0;
+    out[e->N + mx] = 1.0;
+    for (size_t q = 0; q < (size_t)e->E * e->S; q++) out[2 * e->N + q] = (double)e->available[q];
+}
+
 void orc_get_counters(const orc_env *e, orc_counters *out) { *out = e->c; }
 double orc_current_time(const orc_env *e) { return e->current_time; }
 void orc_get_available_slots(const orc_env *e, uint8_t *out) { memcpy(out, e->available, (size_t)e->E * e->S); }
@@ -595,6 +604,17 @@ void orc_run(orc_env *e, int policy, int64_t n_steps, int reset_on_done, const i
             if (tr->holding) tr->holding[i] = s->holding_time;
         }
         if (policy == ORC_POLICY_DEEPRMSA_EXTERNAL) { path = actions_in[i]; slot = 0; }
+        else if (policy == ORC_POLICY_PATH_FF_EXTERNAL) {
+            /* PathOnlyFirstFitAction.action (rmsa_env.py:982-1005) */
+            int a = actions_in[i];
+            path = e->K; slot = e->S;
+            if (a >= 0 && a < e->K) {
+                int gid = path_gid(e, s->src, s->dst, a);
+                int n = number_slots_gid(e, gid);
+                for (int q = 0; q < e->S - n; q++)
+                    if (is_path_free_gid(e, gid, q, n)) { path = a; slot = q; break; }
+            }
+        }
         else if (policy < 0) { path = actions_in[2 * i]; slot = actions_in[2 * i + 1]; }
         else orc_policy(e, policy, &path, &slot);
         if (policy == ORC_POLICY_DEEPRMSA_SP_FF || policy == ORC_POLICY_DEEPRMSA_SAP_FF || policy == ORC_POLICY_DEEPRMSA_EXTERNAL) {

@@ -53,7 +53,8 @@ typedef struct orc_config {
 
 enum { ORC_POLICY_SP_FF = 0, ORC_POLICY_SAP_FF = 1, ORC_POLICY_LLP_FF = 2,
        ORC_POLICY_DEEPRMSA_SP_FF = 3, ORC_POLICY_DEEPRMSA_SAP_FF = 4,
-       ORC_POLICY_DEEPRMSA_EXTERNAL = 5 /* orc_run only: actions_in[i] is a Discrete(k*j) action */ };
+       ORC_POLICY_DEEPRMSA_EXTERNAL = 5, /* orc_run only: actions_in[i] is a Discrete(k*j) action */
+       ORC_POLICY_PATH_FF_EXTERNAL = 6   /* orc_run only: actions_in[i] is a path index, PathOnlyFirstFitAction (rmsa_env.py:974-1008) */ };
 
 #define ORC_MAX_BIT_RATES 64
 
@@ -130,6 +131,9 @@ typedef struct orc_trace {
 } orc_trace;
 void orc_run(orc_env *e, int policy, int64_t n_steps, int reset_on_done, const int32_t *actions_in,
              orc_trace *tr);
+
+/* SimpleMatrixObservation.observation (rmsa_env.py:952-971): 2N one-hot endpoint entries then E*S free flags */
+void orc_simple_matrix_observation(const orc_env *e, double *out);
 
 /* replace libm's log in expovariate (NULL restores it); see orlg_oracle.c */
 void orc_set_log_fn(double (*fn)(double));

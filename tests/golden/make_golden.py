@@ -290,6 +290,33 @@ def gen_rmsa():
               "compactness", out["network_compactness"][-1])
 
 
+# --------------------------------------------------------------------------- RMSA wrappers
+def gen_wrappers():
+    """SimpleMatrixObservation (rmsa_env.py:940-971) and PathOnlyFirstFitAction (:974-1008) on RMSA-v0."""
+    from optical_rl_gym.envs import rmsa_env as R
+    topo = load_pickled_topology(TOPOLOGIES["nsfnet_chen_5-paths_6-modulations"])
+    kw = dict(RMSA_BASE, seed=21, num_spectrum_resources=128, load=40)
+    env = R.PathOnlyFirstFitAction(R.SimpleMatrixObservation(R.RMSAEnv(topology=topo, **kw)))
+    inner = env.env.env
+    arng = np.random.default_rng(77)
+    rec, obs = Recorder(), []
+    for _ in range(600):
+        a = int(arng.integers(0, inner.k_paths + 1))
+        s = inner.current_service
+        resolved = env.action(a)
+        _, reward, done, info = env.step(a)
+        # the gym stand-in's ObservationWrapper does not intercept step(): call the wrapper's observation() directly
+        o = env.env.observation(None)
+        obs.append(np.asarray(o, dtype=np.float64))
+        rec.add(action=a, act_path=int(resolved[0]), act_slot=int(resolved[1]), accepted=bool(s.accepted),
+                reward=float(reward), services_accepted=inner.services_accepted)
+    out = rec.arrays()
+    out["obs"] = np.stack(obs)[:, :].astype(np.uint8)  # values are 0/1
+    out["meta"] = np.array(json.dumps(dict(topology="nsfnet_chen_5-paths_6-modulations", env_kwargs=_jsonable(kw), steps=600)))
+    np.savez_compressed(os.path.join(HERE, "wrappers_nsfnet_s21.npz"), **out)
+    print("wrappers: accepted", int(out["services_accepted"][-1]), "obs dim", out["obs"].shape[1])
+
+
 # --------------------------------------------------------------------------- DeepRMSA traces
 def run_deeprmsa_trace(topo, env_kwargs, policy, n_steps, reset_on_done, actions_seed):
     from optical_rl_gym.envs import deeprmsa_env as D
@@ -567,7 +594,7 @@ def main():
     install_gym_stub()
     import optical_rl_gym  # noqa: F401  (registers env ids)
 
-    todo = [args.only] if args.only else ["topologies", "rmsa", "deeprmsa", "phy", "osnr"]
+    todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "deeprmsa", "phy", "osnr"]
     for what in todo:
         fn = globals().get("gen_" + what)
         if fn is None:
