@@ -276,12 +276,13 @@ def py_random_stream(seed, n):
 
 # ----------------------------------------------------------------------------------------- PhyRMSA oracle
 PHY_MAX_CH = 12
-PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1}
+PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4}
 
 
 class PhyConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
-                ("k_table", C.c_int32), ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
+                ("k_table", C.c_int32), ("grooming", C.c_int32), ("pad0", C.c_int32),
+                ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "link_ends", "path_node_off", "path_nodes")]
 
@@ -302,6 +303,7 @@ class PhyResult(C.Structure):
 PHY_TRACE_FIELDS = [
     ("service_id", np.int32, 1), ("src", np.int32, 1), ("dst", np.int32, 1), ("bit_rate", np.int32, 1),
     ("act_path", np.int32, 1), ("n_channels", np.int32, 1), ("channels", np.int32, PHY_MAX_CH),
+    ("ch_cap", np.int32, PHY_MAX_CH),
     ("arrival", np.float64, 1), ("holding", np.float64, 1), ("ch_used", np.float64, PHY_MAX_CH),
     ("accepted", np.uint8, 1), ("done", np.uint8, 1),
     ("services_accepted", np.int64, 1), ("total_modulation_level", np.int64, 1), ("channels_accepted", np.int64, 1),
@@ -342,7 +344,7 @@ class PhyOracleEnv:
 
     def __init__(self, tables, *, num_channels, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
                  arrival_lambda, holding_lambda, pair_table_row, modulation_level, gsnr, link_ends, path_node_off,
-                 path_nodes, seed=41, asan=False):
+                 path_nodes, grooming=False, seed=41, asan=False):
         self.L = _phy_lib(asan)
         self._keep = []
 
@@ -361,6 +363,7 @@ class PhyOracleEnv:
         c = PhyConfig()
         c.num_channels, c.episode_length, c.num_bit_rates = int(num_channels), int(episode_length), len(bit_rates)
         c.k_table = int(np.asarray(modulation_level).shape[2])
+        c.grooming = 1 if grooming else 0
         c.arrival_lambda, c.holding_lambda = float(arrival_lambda), float(holding_lambda)
         c.bit_rates = keep(bit_rates, np.int32)
         c.bit_rate_cum = keep(bit_rate_cum, np.float64)

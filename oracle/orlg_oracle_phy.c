@@ -3,15 +3,14 @@
  *
  * CPU restatement of the QoT-aware environment's core, optical_rl_gym/envs/phy_rmsa_env.py (PhyRMSAEnv),
  * in the reference's own representation (one byte per (link, channel), run-length encoding along the
- * link axis for the cut / RSS fragmentation metrics, a binary heap of release events).  Scope: the
- * physical layer as the reference's live experiment configuration runs it
- * (tests/test_rmsa_threads_us.py:133-148: grooming=False, heuristics phy_aware_bmfa_rmsa /
- * phy_aware_bmfa_rss_rmsa).  With grooming off the residual-capacity lists (channel_state) are written but
- * never read, and every channel of a service is returned on release (phy_rmsa_env.py:781-861 with
- * result[1] == channel[1] always true), so they are not kept here.  The virtual (grooming) layer and the
- * periodic defragmentation (phy_rmsa_env.py:355-417, 625-764) are NOT restated yet.
+ * link axis for the cut / RSS fragmentation metrics, a binary heap of release events, ordered
+ * residual-capacity lists channel_state[src, dst, k-path] for the virtual "grooming" layer).  Heuristics:
+ * phy_aware_bmfa_rmsa / phy_aware_bmfa_rss_rmsa (which honour env.grooming) and sapff_rmsa /
+ * phy_aware_bmff_rmsa / phy_aware_sapbm_rmsa (which ALWAYS try use_existing_channels first, whatever
+ * env.grooming says: phy_rmsa_env.py:1256,1321,1678).  NOT restated: the periodic defragmentation
+ * (defrag_period, phy_rmsa_env.py:355-417, 662-764).
  *
- * Pinned bit for bit (floats included) against tests/golden/phy_*_bmfa*.npz recorded from the reference.
+ * Pinned bit for bit (floats included) against tests/golden/phy_*.npz recorded from the reference.
  */
 #include "orlg_oracle_phy.h"
 
@@ -21,12 +20,16 @@ typedef struct pservice {
     int32_t service_id, src, dst, bit_rate, br_index;
     double arrival_time, holding_time;
     int32_t path_gid, idp, nch;
-    int32_t ch[ORC_PHY_MAX_CH];
-    int32_t accepted;
+    int32_t ch[ORC_PHY_MAX_CH], used[ORC_PHY_MAX_CH], cap[ORC_PHY_MAX_CH];
+    int32_t accepted, virtual_layer;
     int64_t seq;
 } pservice;
 
 typedef struct { double time; pservice *svc; } pevent;
+
+/* one tuple of channel_state[src, dst, idp]: (channel number, used, free, capacity) in 100 Gb/s units */
+typedef struct { int ch, used, free_, cap; } cs_entry;
+typedef struct { cs_entry *e; int n, capn; } cs_list;
 
 struct orc_phy_env {
     orc_topology topo;
@@ -48,12 +51,24 @@ struct orc_phy_env {
     pevent *heap;
     int n_heap, cap_heap;
     int64_t seq;
+    cs_list *cs;        /* [N*N*K] */
     uint8_t *col, *col2;
     int *r_start, *r_len;
     uint8_t *r_val;
 };
 
 static int ppath_gid(const orc_phy_env *e, int s, int d, int idp) { return e->topo.pair_path_base[s * e->N + d] + idp; }
+
+static cs_list *cs_of(orc_phy_env *e, int src, int dst, int idp) { return &e->cs[((size_t)src * e->N + dst) * e->K + idp]; }
+static void cs_append(cs_list *l, cs_entry v) {
+    if (l->n == l->capn) { l->capn = l->capn ? 2 * l->capn : 8; l->e = (cs_entry *)realloc(l->e, sizeof(cs_entry) * l->capn); }
+    l->e[l->n++] = v;
+}
+static int cs_find(const cs_list *l, int ch) {
+    for (int i = 0; i < l->n; i++) if (l->e[i].ch == ch) return i;
+    return -1;
+}
+static void cs_remove(cs_list *l, int i) { memmove(&l->e[i], &l->e[i + 1], sizeof(cs_entry) * (l->n - i - 1)); l->n--; }
 
 static int prle(const uint8_t *a, int n, int *starts, uint8_t *values, int *lengths) {
     if (n == 0) return 0;
@@ -180,10 +195,27 @@ static pevent pheap_pop(orc_phy_env *e) {
     return top;
 }
 
-/* phy_rmsa_env.py:781-861 with grooming off: every channel of the service is returned */
+/* phy_rmsa_env.py:781-861 */
+static void free_channel_on_path(orc_phy_env *e, int gid, int ch) {
+    for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+        e->avail[(size_t)e->topo.path_links[h] * e->C + ch] = 1;
+}
 static void release_path(orc_phy_env *e, pservice *s) {
-    for (int h = e->topo.path_link_off[s->path_gid]; h < e->topo.path_link_off[s->path_gid + 1]; h++)
-        for (int i = 0; i < s->nch; i++) e->avail[(size_t)e->topo.path_links[h] * e->C + s->ch[i]] = 1;
+    for (int i = 0; i < s->nch; i++)
+        if (s->used[i] == s->cap[i]) free_channel_on_path(e, s->path_gid, s->ch[i]);
+    cs_list *l = cs_of(e, s->src, s->dst, s->idp);
+    for (int i = 0; i < s->nch; i++)
+        if (s->used[i] != s->cap[i]) {
+            int q = cs_find(l, s->ch[i]);
+            cs_entry r = l->e[q];
+            cs_remove(l, q);
+            if (r.used == s->used[i]) {  /* this service was the channel's last user */
+                free_channel_on_path(e, s->path_gid, s->ch[i]);
+            } else {
+                cs_entry u = { r.ch, r.used - s->used[i], r.free_ + s->used[i], r.cap };
+                cs_append(l, u);
+            }
+        }
     for (int i = 0; i < e->n_running; i++)
         if (e->running[i] == s) {
             memmove(&e->running[i], &e->running[i + 1], sizeof(pservice *) * (e->n_running - i - 1));
@@ -243,6 +275,7 @@ void orc_phy_reset(orc_phy_env *e, int only_episode_counters) {
     e->current_time = 0;
     memset(&e->c, 0, sizeof(e->c));
     memset(e->avail, 1, (size_t)e->E * e->C);
+    for (size_t i = 0; i < (size_t)e->N * e->N * e->K; i++) e->cs[i].n = 0;
     e->new_service = 0;
     next_service(e);
 }
@@ -260,6 +293,7 @@ orc_phy_env *orc_phy_create(const orc_topology *topo, const orc_phy_config *cfg,
         e->link_of[a * e->N + b] = l;
         e->link_of[b * e->N + a] = l;
     }
+    e->cs = (cs_list *)calloc((size_t)e->N * e->N * e->K, sizeof(cs_list));
     e->col = (uint8_t *)malloc(e->E); e->col2 = (uint8_t *)malloc(e->E);
     e->r_start = (int *)malloc(sizeof(int) * (e->E + 1));
     e->r_len = (int *)malloc(sizeof(int) * (e->E + 1));
@@ -272,6 +306,8 @@ void orc_phy_destroy(orc_phy_env *e) {
     if (!e) return;
     for (int i = 0; i < e->n_heap; i++) free(e->heap[i].svc);
     if (e->current && !e->current->accepted) free(e->current);
+    for (size_t i = 0; i < (size_t)e->N * e->N * e->K; i++) free(e->cs[i].e);
+    free(e->cs);
     free(e->heap); free(e->running); free(e->avail); free(e->link_of); free(e->col); free(e->col2);
     free(e->r_start); free(e->r_len); free(e->r_val);
     free(e);
@@ -283,24 +319,64 @@ void orc_phy_get_request(const orc_phy_env *e, orc_request *o) {
     o->holding_time = e->current->holding_time;
 }
 
-/* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438, metric = calculate_r_cut modified) and
- * phy_aware_bmfa_rss_rmsa (:1441-1505, metric = calculate_r_spatial), grooming off */
+/* the heuristics of phy_rmsa_env.py:1254-1737.  All build, per candidate path ("row"), the list of free channels
+ * (level, [metric,] channel, idp), sort it, pick a row and take its channels in order until the bit rate is covered. */
 typedef struct { int mod; double frag; int ch, idp, pos; uint8_t key0; } cand;
-static int cand_cmp(const void *a, const void *b) {
+static int cmp_level_frag(const void *a, const void *b) { /* key (-x[0], -x[1]); -np.uint8 wraps (key0); stable */
     const cand *x = (const cand *)a, *y = (const cand *)b;
-    /* key (-x[0], -x[1]): -np.uint8 wraps (key0), -frag ascending = frag descending; stable */
     if (x->key0 != y->key0) return x->key0 < y->key0 ? -1 : 1;
     if (x->frag != y->frag) return x->frag > y->frag ? -1 : 1;
     return x->pos - y->pos;
+}
+static int cmp_level_ch(const void *a, const void *b) { /* key (-x[0], x[1]) */
+    const cand *x = (const cand *)a, *y = (const cand *)b;
+    if (x->key0 != y->key0) return x->key0 < y->key0 ? -1 : 1;
+    return x->ch - y->ch;
+}
+
+/* use_existing_channels (phy_rmsa_env.py:1650-1673): residual capacity of partially used channels between the
+ * same (source, destination, k-path); returns 1 and fills act (path = idp + 20) when the request fits */
+static int use_existing_channels(orc_phy_env *e, orc_phy_action *act) {
+    const pservice *s = e->current;
+    double unassigned = s->bit_rate;
+    int n = 0;
+    for (int idp = 0; idp < e->K; idp++) {
+        const cs_list *l = cs_of(e, s->src, s->dst, idp);
+        int sum = 0;
+        for (int i = 0; i < l->n; i++) sum += l->e[i].free_;
+        if ((double)sum >= unassigned / 100) {
+            for (int i = 0; i < l->n && n < ORC_PHY_MAX_CH; i++) {
+                const cs_entry *c = &l->e[i];
+                if (c->free_ > 0) {
+                    unassigned -= c->free_ * 100;
+                    act->ch[n] = c->ch; act->cap[n] = c->cap;
+                    if (unassigned <= 0) {
+                        act->used[n] = c->free_ + unassigned / 100; act->free_[n] = unassigned / -100;
+                        act->path = idp + 20; act->n = n + 1;
+                        return 1;
+                    }
+                    act->used[n] = c->free_; act->free_[n] = 0;
+                    n++;
+                }
+            }
+        }
+    }
+    return 0;
 }
 
 void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
     const pservice *s = e->current;
     int K = e->K, C = e->C;
+    act->path = -2; act->n = 0;
+    /* bmfa / bmfa_rss consult the virtual layer only when env.grooming; the other three always do */
+    const int groom = (policy == ORC_PHY_POLICY_BMFA || policy == ORC_PHY_POLICY_BMFA_RSS) ? e->cfg.grooming : 1;
+    if (groom && use_existing_channels(e, act)) return;
+    act->path = -2; act->n = 0;
     int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
     cand *rows = (cand *)malloc(sizeof(cand) * (size_t)K * C);
     int *cnt = (int *)calloc(K, sizeof(int));
     int *alive = (int *)malloc(sizeof(int) * K);
+    const int with_metric = policy == ORC_PHY_POLICY_BMFA || policy == ORC_PHY_POLICY_BMFA_RSS;
     for (int idp = 0; idp < K; idp++) {
         int gid = ppath_gid(e, s->src, s->dst, idp);
         alive[idp] = 1;
@@ -308,21 +384,29 @@ void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
             if (is_channel_free(e, gid, ch)) {
                 cand *c = &rows[(size_t)idp * C + cnt[idp]];
                 c->mod = e->cfg.modulation_level[((size_t)row * C + ch) * e->cfg.k_table + idp];
-                c->frag = policy == ORC_PHY_POLICY_BMFA_RSS ? r_spatial(e, gid, ch) : (double)r_cut_modified(e, gid, ch);
+                c->frag = !with_metric ? 0.0 : policy == ORC_PHY_POLICY_BMFA_RSS ? r_spatial(e, gid, ch) : (double)r_cut_modified(e, gid, ch);
                 c->ch = ch; c->idp = idp; c->pos = cnt[idp]; c->key0 = (uint8_t)(-c->mod);
                 cnt[idp]++;
             }
-        qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cand_cmp);
+        if (with_metric) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_level_frag);
+        else if (policy != ORC_PHY_POLICY_SAPFF) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_level_ch);
+        /* sapff: key x[1] = channel, already ascending */
     }
-    act->path = -2; act->n = 0;
     for (;;) {
-        double max_mod = -INFINITY, max_frag = -INFINITY;
         int best = -1;
-        for (int i = 0; i < K; i++) {
-            if (!alive[i] || cnt[i] == 0) continue;
-            const cand *h = &rows[(size_t)i * C];
-            if ((double)h->mod > max_mod || ((double)h->mod == max_mod && h->frag > max_frag)) {
-                max_mod = h->mod; max_frag = h->frag; best = i;
+        if (policy == ORC_PHY_POLICY_SAPFF || policy == ORC_PHY_POLICY_SAPBM) {
+            /* empty rows are dropped, the first remaining row is used (phy_rmsa_env.py:1289-1297, 1711-1719) */
+            for (int i = 0; i < K && best < 0; i++)
+                if (alive[i] && cnt[i] > 0) best = i;
+        } else {
+            double max_mod = -INFINITY, max_frag = -INFINITY;
+            for (int i = 0; i < K; i++) {
+                if (!alive[i] || cnt[i] == 0) continue;
+                const cand *h = &rows[(size_t)i * C];
+                /* bmff: ties keep the lower row index (:1352-1355); bmfa: ties broken by the metric (:1416-1421) */
+                if ((double)h->mod > max_mod || (with_metric && (double)h->mod == max_mod && h->frag > max_frag)) {
+                    max_mod = h->mod; max_frag = h->frag; best = i;
+                }
             }
         }
         if (best < 0) break;
@@ -346,40 +430,70 @@ void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
     free(rows); free(cnt); free(alive);
 }
 
-/* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424), physical layer */
+static void running_add(orc_phy_env *e, pservice *s) {
+    if (e->n_running == e->cap_running) {
+        e->cap_running = e->cap_running ? 2 * e->cap_running : 1024;
+        e->running = (pservice **)realloc(e->running, sizeof(pservice *) * e->cap_running);
+    }
+    e->running[e->n_running++] = s;
+}
+
+/* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424) without the periodic defragmentation */
 void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out) {
     pservice *s = e->current;
-    s->accepted = 0;
-    if (act->path != -2 && act->path >= 0 && act->path < e->K) {
-        int gid = ppath_gid(e, s->src, s->dst, act->path);
-        int free_flag = 1; /* is_path_free_on_channels :1019-1027 */
-        for (int i = 0; i < act->n; i++) free_flag &= is_channel_free(e, gid, act->ch[i]);
-        if (free_flag) {
-            /* _provision_path :544-623 */
-            int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
-            for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
-                for (int i = 0; i < act->n; i++) e->avail[(size_t)e->topo.path_links[h] * e->C + act->ch[i]] = 0;
-            for (int i = 0; i < act->n; i++) {
-                double g = e->cfg.gsnr[((size_t)row * e->C + act->ch[i]) * e->cfg.k_table + act->path];
-                e->total_gsnr_episode += g;
-                e->total_modulation_level_episode += act->cap[i];
-                e->channels_accepted_episode += 1;
-                s->ch[i] = act->ch[i];
-            }
-            s->nch = act->n; s->path_gid = gid; s->idp = act->path;
-            if (e->n_running == e->cap_running) {
-                e->cap_running = e->cap_running ? 2 * e->cap_running : 1024;
-                e->running = (pservice **)realloc(e->running, sizeof(pservice *) * e->cap_running);
-            }
-            e->running[e->n_running++] = s;
-            /* _service_acceptance(False) :767-778 */
-            s->accepted = 1;
+    s->accepted = 0; s->virtual_layer = 0;
+    if (act->path != -2) {
+        if (act->path > 10) {
+            /* virtual layer: _service_acceptance(True) then _provision_virtual_path (:280-288, 625-659) */
+            int idp = act->path - 20;
+            s->virtual_layer = 1; s->accepted = 1;
             e->c.services_accepted++; e->c.episode_services_accepted++;
-            e->total_path_length_episode += e->topo.path_length[gid];
-            e->total_path_index_episode += act->path + 1;
-            e->physical_services_accepted_episode += 1;
             e->c.bit_rate_provisioned += s->bit_rate; e->c.episode_bit_rate_provisioned += s->bit_rate;
+            cs_list *l = cs_of(e, s->src, s->dst, idp);
+            for (int i = 0; i < act->n; i++) {
+                int q = cs_find(l, act->ch[i]);
+                cs_entry t = l->e[q];
+                int taken = (int)act->used[i];
+                cs_remove(l, q);
+                cs_entry u = { t.ch, t.used + taken, t.free_ - taken, t.cap };
+                cs_append(l, u);
+                s->ch[i] = act->ch[i]; s->used[i] = taken; s->cap[i] = act->cap[i];
+            }
+            s->nch = act->n; s->idp = idp; s->path_gid = ppath_gid(e, s->src, s->dst, idp);
+            running_add(e, s);
             pheap_push(e, s->arrival_time + s->holding_time, s);
+        } else if (act->path >= 0 && act->path < e->K) {
+            int gid = ppath_gid(e, s->src, s->dst, act->path);
+            int free_flag = 1; /* is_path_free_on_channels :1019-1027 */
+            for (int i = 0; i < act->n; i++) free_flag &= is_channel_free(e, gid, act->ch[i]);
+            if (free_flag) {
+                /* _provision_path :544-623 */
+                int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
+                for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+                    for (int i = 0; i < act->n; i++) e->avail[(size_t)e->topo.path_links[h] * e->C + act->ch[i]] = 0;
+                cs_list *l = cs_of(e, s->src, s->dst, act->path);
+                for (int i = 0; i < act->n; i++) {
+                    double g = e->cfg.gsnr[((size_t)row * e->C + act->ch[i]) * e->cfg.k_table + act->path];
+                    e->total_gsnr_episode += g;
+                    e->total_modulation_level_episode += act->cap[i];
+                    e->channels_accepted_episode += 1;
+                    s->ch[i] = act->ch[i]; s->used[i] = (int)act->used[i]; s->cap[i] = act->cap[i];
+                    if (act->free_[i] != 0) {
+                        cs_entry v = { act->ch[i], (int)act->used[i], (int)act->free_[i], act->cap[i] };
+                        cs_append(l, v);
+                    }
+                }
+                s->nch = act->n; s->path_gid = gid; s->idp = act->path;
+                running_add(e, s);
+                /* _service_acceptance(False) :767-778 */
+                s->accepted = 1;
+                e->c.services_accepted++; e->c.episode_services_accepted++;
+                e->total_path_length_episode += e->topo.path_length[gid];
+                e->total_path_index_episode += act->path + 1;
+                e->physical_services_accepted_episode += 1;
+                e->c.bit_rate_provisioned += s->bit_rate; e->c.episode_bit_rate_provisioned += s->bit_rate;
+                pheap_push(e, s->arrival_time + s->holding_time, s);
+            }
         }
     }
     if (out) {
@@ -433,6 +547,8 @@ void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done,
                 for (int q = 0; q < ORC_PHY_MAX_CH; q++) tr->channels[i * ORC_PHY_MAX_CH + q] = q < act.n ? act.ch[q] : -1;
             if (tr->ch_used)
                 for (int q = 0; q < ORC_PHY_MAX_CH; q++) tr->ch_used[i * ORC_PHY_MAX_CH + q] = q < act.n ? act.used[q] : 0.0;
+            if (tr->ch_cap)
+                for (int q = 0; q < ORC_PHY_MAX_CH; q++) tr->ch_cap[i * ORC_PHY_MAX_CH + q] = q < act.n ? act.cap[q] : 0;
             if (tr->accepted) tr->accepted[i] = (uint8_t)r.accepted;
             if (tr->done) tr->done[i] = (uint8_t)r.done;
             if (tr->services_accepted) tr->services_accepted[i] = e->c.services_accepted;

@@ -17,6 +17,8 @@ typedef struct orc_phy_config {
     int32_t episode_length;
     int32_t num_bit_rates;
     int32_t k_table;        /* number of k-path columns in the QoT tables */
+    int32_t grooming;       /* env.grooming (phy_rmsa_env.py:57): consulted by bmfa / bmfa_rss only */
+    int32_t pad0;
     double arrival_lambda, holding_lambda;
     const int32_t *bit_rates;
     const double *bit_rate_cum, *src_cum, *dst_cum;
@@ -28,10 +30,11 @@ typedef struct orc_phy_config {
     const int32_t *path_nodes;       /* node ids along every path */
 } orc_phy_config;
 
-enum { ORC_PHY_POLICY_BMFA = 0, ORC_PHY_POLICY_BMFA_RSS = 1 };
+enum { ORC_PHY_POLICY_BMFA = 0, ORC_PHY_POLICY_BMFA_RSS = 1, ORC_PHY_POLICY_SAPFF = 2, ORC_PHY_POLICY_BMFF = 3,
+       ORC_PHY_POLICY_SAPBM = 4 };
 
 typedef struct orc_phy_action {
-    int32_t path;   /* -2 = blocked */
+    int32_t path;   /* -2 = blocked; 20 + idp = served on the virtual layer (phy_rmsa_env.py:280-288) */
     int32_t n;
     int32_t ch[ORC_PHY_MAX_CH], cap[ORC_PHY_MAX_CH];
     double used[ORC_PHY_MAX_CH], free_[ORC_PHY_MAX_CH];
@@ -47,7 +50,7 @@ typedef struct orc_phy_result {
 } orc_phy_result;
 
 typedef struct orc_phy_trace {
-    int32_t *service_id, *src, *dst, *bit_rate, *act_path, *n_channels, *channels;
+    int32_t *service_id, *src, *dst, *bit_rate, *act_path, *n_channels, *channels, *ch_cap;
     double *arrival, *holding, *ch_used;
     uint8_t *accepted, *done;
     int64_t *services_accepted, *total_modulation_level, *channels_accepted, *path_index, *physical_paths,

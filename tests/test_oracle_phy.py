@@ -7,7 +7,7 @@ import pytest
 
 from conftest import GOLDEN, load_golden, load_phy_tables, load_topology, phy_oracle_from_kwargs
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "phy_*_bmfa*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "phy_*.npz")))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -24,6 +24,7 @@ def test_phy_trace_bit_exact(case):
     assert np.array_equal(tr["n_channels"], z["n_channels"])
     assert np.array_equal(tr["channels"], z["channels"].astype(np.int32))
     assert np.array_equal(tr["ch_used"], z["ch_used"])
+    assert np.array_equal(tr["ch_cap"], z["ch_cap"].astype(np.int32))
     for f in ("accepted", "done", "services_accepted", "path_index", "physical_paths", "n_running", "free_total"):
         assert np.array_equal(tr[f].astype(np.int64), z[f].astype(np.int64)), f
     for f in ("number_cuts_total", "rss_total_metric", "total_path_length", "avrage_gsnr", "average_path_index",
