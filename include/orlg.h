@@ -186,10 +186,12 @@ int orlg_simple_matrix_obs_dim(orlg_env *env);
 int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */);
 
 /* ------------------------------------------------------------------------------------------------
- * QoT-aware environment, physical layer: PhyRMSAEnv (optical_rl_gym/envs/phy_rmsa_env.py) as the reference's live
- * experiment configuration runs it (tests/test_rmsa_threads_us.py:133-148: grooming=False, no periodic
- * defragmentation).  Allocation is per CHANNEL (L+C+S bands = 268 channels, non-contiguous); the QoT gate is the
- * table modulation_level[pair row][channel][k-path] (capacity = level x 100 Gb/s); GSNR[...] feeds the statistics.
+ * QoT-aware environment: PhyRMSAEnv (optical_rl_gym/envs/phy_rmsa_env.py), physical layer + virtual ("grooming")
+ * layer, without the periodic defragmentation (defrag_period).  Allocation is per CHANNEL (L+C+S bands = 268
+ * channels, non-contiguous); the QoT gate is the table modulation_level[pair row][channel][k-path] (capacity = level
+ * x 100 Gb/s); GSNR[...] feeds the statistics.  A service that does not use the whole capacity of its last channel
+ * leaves the rest in channel_state[src, dst, k-path] (phy_rmsa_env.py:600-602), where use_existing_channels (:1650-1673)
+ * finds it for later requests of the same (source, destination, k-path): action path = 20 + k-path (:280-288).
  */
 typedef struct orlg_phy_config {
     int32_t num_channels;     /* 2*number_spectrum_channels + number_spectrum_channels_s_band (optical_network_env.py:78-84) */
@@ -198,6 +200,9 @@ typedef struct orlg_phy_config {
     int32_t k_table;          /* k-path columns of the tables (>= topology k_paths) */
     int32_t num_table_rows;
     int32_t queue_capacity;   /* running services per env, multiple of 64; 0 = from the load */
+    int32_t grooming;         /* env.grooming (phy_rmsa_env.py:57): bmfa / bmfa_rss consult the virtual layer only when set;
+                               * sapff / bmff / sapbm always do (:1256, 1321, 1678) */
+    int32_t channel_state_capacity; /* entries per channel_state[src, dst, k-path] list (8..64); 0 = from the load */
     double arrival_lambda, holding_lambda;
     const int32_t *bit_rates;           /* [num_bit_rates], default 100..600 (phy_rmsa_env.py:38) */
     const double *bit_rate_cum, *src_cum, *dst_cum;
@@ -211,8 +216,11 @@ typedef struct orlg_phy_config {
 
 enum {
     ORLG_PHY_POLICY_EXTERNAL = -1, /* caller supplies (path, channels) per env */
-    ORLG_PHY_POLICY_BMFA_CUT = 0,  /* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438), grooming off */
-    ORLG_PHY_POLICY_BMFA_RSS_METRIC = 1, /* phy_aware_bmfa_rss_rmsa (phy_rmsa_env.py:1441-1505), grooming off */
+    ORLG_PHY_POLICY_BMFA_CUT = 0,  /* phy_aware_bmfa_rmsa (phy_rmsa_env.py:1375-1438) */
+    ORLG_PHY_POLICY_BMFA_RSS_METRIC = 1, /* phy_aware_bmfa_rss_rmsa (phy_rmsa_env.py:1441-1505) */
+    ORLG_PHY_POLICY_SAPFF = 2,     /* sapff_rmsa (phy_rmsa_env.py:1676-1737) */
+    ORLG_PHY_POLICY_BMFF = 3,      /* phy_aware_bmff_rmsa (phy_rmsa_env.py:1317-1372) */
+    ORLG_PHY_POLICY_SAPBM = 4,     /* phy_aware_sapbm_rmsa (phy_rmsa_env.py:1254-1314) */
 };
 #define ORLG_PHY_MAX_CHANNELS 14 /* channels per service */
 
@@ -225,6 +233,7 @@ typedef struct orlg_phy_step_io { /* optional per-step outputs, [n_steps][B] eac
     double *arrival, *holding;
     double *number_cuts_total;  /* info["number_cuts_total"] (_calculate_total_cuts, phy_rmsa_env.py:1195-1203) */
     double *rss_total_metric;   /* info["rss_total_metric"] (calculate_total_r_spatial, :1110-1121) */
+    int16_t *channels_used;     /* [n_steps][B][ORLG_PHY_MAX_CHANNELS] share of each channel the service uses, 100 Gb/s units */
 } orlg_phy_step_io;
 
 typedef struct orlg_phy_episode_stats { /* per-episode sums behind the info dict (phy_rmsa_env.py:339-347) */
@@ -242,8 +251,10 @@ int orlg_phy_destroy(orlg_phy_env *env);
 int orlg_phy_set_stream(orlg_phy_env *env, void *hip_stream);
 int orlg_phy_synchronize(orlg_phy_env *env);
 int orlg_phy_reset(orlg_phy_env *env, int32_t only_episode_counters);
-/* n_steps x { action = policy(env); env.step(action) } (phy_rmsa_env.py:272-351).  EXTERNAL: act_path [B] and
- * act_channels [B][ORLG_PHY_MAX_CHANNELS] (-1 padded), n_steps == 1. */
+/* n_steps x { action = policy(env); env.step(action) } (phy_rmsa_env.py:272-351).  EXTERNAL: n_steps == 1, act_path
+ * [B] (-2 = blocked, 0..k-1 = physical path, 20 + k-path = virtual layer) and act_channels [B][ORLG_PHY_MAX_CHANNELS]
+ * (-1 padded), entry = channel | used << 9 with `used` the share of the channel the service takes in 100 Gb/s units
+ * (the reference's selected_channels tuple fields 0 and 1; used == 0 means the channel's whole capacity). */
 int orlg_phy_step(orlg_phy_env *env, int32_t policy, int32_t n_steps, const int32_t *act_path,
                   const int16_t *act_channels, int32_t auto_reset, const orlg_phy_step_io *io);
 int orlg_phy_words_per_link(orlg_phy_env *env);
@@ -255,6 +266,10 @@ int orlg_phy_get_episode_stats(orlg_phy_env *env, orlg_phy_episode_stats *out /*
 /* topology.graph["available_channels"] as a bitmap [B][E][W] uint64 */
 int orlg_phy_get_occupancy(orlg_phy_env *env, uint64_t *out);
 int orlg_phy_reduce_counters(orlg_phy_env *env, int64_t *out /* [16] as orlg_reduce_counters */);
+/* env.channel_state[src_id, dst_id, k-path] of ONE env (phy_rmsa_env.py:117-125): entries [N*N*K][capacity] packed
+ * channel | used << 9 | free << 14 | capacity << 19 (100 Gb/s units) in list order, lengths [N*N*K]; returns capacity */
+int orlg_phy_get_channel_state(orlg_phy_env *env, int32_t env_index, uint32_t *entries, uint8_t *lengths);
+int orlg_phy_channel_state_capacity(orlg_phy_env *env);
 
 /* ------------------------------------------------------------------------------------------------
  * GN-model GSNR admission check: calculate_osnr (examples/calculate_osnr.py:9-56) for a flattened batch of checks.

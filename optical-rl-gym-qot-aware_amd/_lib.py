@@ -52,6 +52,7 @@ STEP_IO_DTYPES = {"act_path": "int32", "act_slot": "int32", "accepted": "uint8",
 class PhyConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
                 ("k_table", C.c_int32), ("num_table_rows", C.c_int32), ("queue_capacity", C.c_int32),
+                ("grooming", C.c_int32), ("channel_state_capacity", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight")]
@@ -59,14 +60,15 @@ class PhyConfig(C.Structure):
 
 class PhyStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_path", "n_channels", "channels", "accepted", "done", "request",
-                                         "arrival", "holding", "number_cuts_total", "rss_total_metric")]
+                                         "arrival", "holding", "number_cuts_total", "rss_total_metric",
+                                         "channels_used")]
 
 
 PHY_MAX_CHANNELS = 14
 PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
                       "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
-                      "number_cuts_total": "float64", "rss_total_metric": "float64"}
-PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1}
+                      "number_cuts_total": "float64", "rss_total_metric": "float64", "channels_used": "int16"}
+PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4}
 
 _lib = None
 
@@ -122,6 +124,8 @@ def load(build_if_missing=True):
                  "orlg_phy_get_num_running", "orlg_phy_get_episode_stats", "orlg_phy_get_occupancy",
                  "orlg_phy_reduce_counters"):
         getattr(L, name).argtypes = [vp, vp]
+    L.orlg_phy_get_channel_state.argtypes = [vp, i32, vp, vp]
+    L.orlg_phy_channel_state_capacity.argtypes = [vp]
     L.orlg_host_log.argtypes = [C.c_double]
     L.orlg_host_log.restype = C.c_double
     _lib = L
@@ -138,7 +142,8 @@ EXPORTED_SYMBOLS = [
     "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
-    "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_gn_osnr",
+    "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_phy_get_channel_state",
+    "orlg_phy_channel_state_capacity", "orlg_gn_osnr",
 ]
 
 

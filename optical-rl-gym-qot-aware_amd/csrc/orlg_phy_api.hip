@@ -32,6 +32,7 @@ static phy_kernel_t pick_phy(int W) {
 __global__ void orlg_phy_clear_kernel(OrlgPhyParams p, int W, int keep_rng) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
     for (size_t i = tid; i < (size_t)p.B * p.NW; i += nth) p.occ[i] = valid_mask(p.C, (int)(i % W));
+    for (size_t i = tid; i < (size_t)p.B * p.N * p.N * p.K; i += nth) p.cs_n[i] = 0;
     for (size_t i = tid; i < (size_t)p.B; i += nth) {
         OrlgPhyScalars s;
         memset(&s, 0, sizeof(s));
@@ -182,6 +183,23 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     p.B = batch; p.N = N; p.E = E; p.C = C; p.K = K; p.NBR = NBR; p.NW = E * W;
     p.episode_length = c->episode_length; p.num_rows = c->num_table_rows; p.cpad = W * 64;
     p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
+    p.grooming = c->grooming ? 1 : 0;
+    {
+        // channel_state[src, dst, k-path] lists (virtual layer): one entry per lit, partially used channel of the
+        // (pair, path); sized from the mean number of services per ordered pair, overflow is reported, never dropped
+        int cl = c->channel_state_capacity;
+        if (cl <= 0) {
+            double m = (c->arrival_lambda / c->holding_lambda) / ((double)N * (N - 1));
+            cl = (int)(m + 6.0 * std::sqrt(m) + 8.0);
+        }
+        int pw2 = 8;
+        while (pw2 < cl) pw2 <<= 1;
+        if (pw2 > ORLG_CS_MAX) {
+            if (c->channel_state_capacity > ORLG_CS_MAX) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "channel_state_capacity %d exceeds %d", cl, ORLG_CS_MAX); }
+            pw2 = ORLG_CS_MAX;
+        }
+        p.cs_len = pw2;
+    }
     // release queue: at most Poisson(load) services in progress, and never more than the channel-links can hold
     int Q = c->queue_capacity;
     if (Q <= 0) {
@@ -254,6 +272,19 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         for (size_t k = 0; k < sq.size(); k++) sq[k] = std::sqrt((double)k);
         p.t_sqrt = put(sq.data(), sq.size() * 8);
         p.t_plen = put(t->path_length, (size_t)t->num_paths * 8);
+        {
+            // record -> the unordered node pair it serves (ksp[a, b] and ksp[b, a] are the same records)
+            std::vector<uint16_t> pp(t->num_paths, 0);
+            for (int a = 0; a < N; a++)
+                for (int b = a + 1; b < N; b++) {
+                    if (t->pair_path_base[a * N + b] != t->pair_path_base[b * N + a]) {
+                        orlg_phy_destroy(e);
+                        return fail(ORLG_ERR_INVALID, "pair (%d,%d) and (%d,%d) must share their path records", a, b, b, a);
+                    }
+                    for (int k = 0; k < K; k++) pp[t->pair_path_base[a * N + b] + k] = (uint16_t)(a * N + b);
+                }
+            p.t_pathpair = put(pp.data(), pp.size() * 2);
+        }
         p.tab_bytes = (int32_t)blob.size();
         p.l_outs = p.tab_bytes;
         p.l_shared_bytes = p.tab_bytes + up16(ORLG_PHY_NUM_OUTS * 8);
@@ -299,6 +330,8 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     TRY(alloc(reinterpret_cast<void **>(&p.qrec), (size_t)batch * Q * sizeof(OrlgPhySvc)));
     TRY(alloc(reinterpret_cast<void **>(&p.mt), (size_t)batch * ORLG_MT_N * 4));
     TRY(alloc(reinterpret_cast<void **>(&p.scal), (size_t)batch * sizeof(OrlgPhyScalars)));
+    TRY(alloc(reinterpret_cast<void **>(&p.cs), (size_t)batch * N * N * K * p.cs_len * 4));
+    TRY(alloc(reinterpret_cast<void **>(&p.cs_n), (size_t)batch * N * N * K));
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
         for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
@@ -351,7 +384,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
                   int32_t auto_reset, const orlg_phy_step_io *io) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     if (n_steps < 1) return fail(ORLG_ERR_INVALID, "n_steps must be >= 1");
-    if (policy != ORLG_PHY_POLICY_EXTERNAL && policy != ORLG_PHY_POLICY_BMFA_CUT && policy != ORLG_PHY_POLICY_BMFA_RSS_METRIC) return fail(ORLG_ERR_INVALID, "unknown PhyRMSA policy %d", policy);
+    if (policy < ORLG_PHY_POLICY_EXTERNAL || policy > ORLG_PHY_POLICY_SAPBM) return fail(ORLG_ERR_INVALID, "unknown PhyRMSA policy %d", policy);
     if (policy == ORLG_PHY_POLICY_EXTERNAL && (!act_path || !act_channels || n_steps != 1))
         return fail(ORLG_ERR_INVALID, "external actions need path and channel arrays and n_steps == 1");
     HIP_TRY(hipSetDevice(e->device));
@@ -376,7 +409,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
         {io ? io->act_path : nullptr, 4},  {io ? io->n_channels : nullptr, 4}, {io ? io->channels : nullptr, 2 * ORLG_PHY_MAX_CH},
         {io ? io->accepted : nullptr, 1},  {io ? io->done : nullptr, 1},       {io ? io->request : nullptr, 16},
         {io ? io->arrival : nullptr, 8},   {io ? io->holding : nullptr, 8},    {io ? io->number_cuts_total : nullptr, 8},
-        {io ? io->rss_total_metric : nullptr, 8}};
+        {io ? io->rss_total_metric : nullptr, 8}, {io ? io->channels_used : nullptr, 2 * ORLG_PHY_MAX_CH}};
     bool staged[ORLG_PHY_NUM_OUTS] = {false};
     p.out_mask = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) {
@@ -447,6 +480,17 @@ int orlg_phy_get_occupancy(orlg_phy_env *e, uint64_t *out) {
     HIP_TRY(hipMemcpyAsync(out, e->p.occ, (size_t)e->p.B * e->p.NW * 8, hipMemcpyDefault, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return ORLG_OK;
+}
+int orlg_phy_channel_state_capacity(orlg_phy_env *e) { return e ? e->p.cs_len : ORLG_ERR_INVALID; }
+int orlg_phy_get_channel_state(orlg_phy_env *e, int32_t env_index, uint32_t *entries, uint8_t *lengths) {
+    if (!e || !entries || !lengths) return fail(ORLG_ERR_INVALID, "null argument");
+    if (env_index < 0 || env_index >= e->p.B) return fail(ORLG_ERR_INVALID, "env_index %d out of range", env_index);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t lists = (size_t)e->p.N * e->p.N * e->p.K;
+    HIP_TRY(hipMemcpyAsync(entries, e->p.cs + (size_t)env_index * lists * e->p.cs_len, lists * e->p.cs_len * 4, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipMemcpyAsync(lengths, e->p.cs_n + (size_t)env_index * lists, lists, hipMemcpyDefault, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return e->p.cs_len;
 }
 int orlg_phy_reduce_counters(orlg_phy_env *e, int64_t *out) {
     if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");

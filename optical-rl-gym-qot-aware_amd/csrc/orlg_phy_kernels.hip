@@ -1,10 +1,11 @@
 // orlg_phy_kernels.hip -- gfx950 kernels of the QoT-aware (PhyRMSA) step() path, physical layer.
 //
-// Reference: optical_rl_gym/envs/phy_rmsa_env.py -- step :272-351, _provision_path :544-623,
-// _service_acceptance :767-778, _release_path :781-861, _next_service :969-1017, is_channel_free :1029-1035,
-// calculate_r_cut (modified) :1123-1193, _calculate_total_cuts :1195-1203, calculate_total_r_spatial :1110-1121,
-// phy_aware_bmfa_rmsa :1375-1438.  Scope = the reference's live experiment configuration
-// (tests/test_rmsa_threads_us.py:133-148): grooming=False, no periodic defragmentation.
+// Reference: optical_rl_gym/envs/phy_rmsa_env.py -- step :272-351, _provision_path :544-623, _provision_virtual_path
+// :625-659, _service_acceptance :767-778, _release_path :781-861, _next_service :969-1017, is_channel_free :1029-1035,
+// calculate_r_cut (modified) :1123-1193, calculate_r_spatial :1085-1108, _calculate_total_cuts :1195-1203,
+// calculate_total_r_spatial :1110-1121, heuristics phy_aware_sapbm_rmsa :1254, phy_aware_bmff_rmsa :1317,
+// phy_aware_bmfa_rmsa :1375, phy_aware_bmfa_rss_rmsa :1441, use_existing_channels :1650, sapff_rmsa :1676.
+// Not built: the periodic defragmentation (defrag_period, :355-417, 662-764).
 //
 // Same execution model as orlg_kernels.hip: one wavefront per environment, the link x channel free bitmap
 // (268 channels = 5 words per link), the release-time array and the MT19937 state live in LDS for the whole
@@ -20,9 +21,18 @@
 
 struct __attribute__((aligned(16))) OrlgPhySvc {  // one running service (HBM)
     uint16_t gid;
-    uint8_t nch, pad;
-    uint16_t ch[ORLG_PHY_MAX_CH];
+    uint8_t nch, flags;            // flags bit 0: served on the virtual layer; bit 1: source index > destination index
+    uint16_t ch[ORLG_PHY_MAX_CH];  // channel | used << 9 | partial << 14  (partial: used != capacity)
 };
+#define ORLG_CS_MAX 64             // entries per channel_state[src, dst, k-path] list: p.cs_len <= one wavefront
+// one channel_state tuple (channel, used, free, capacity), 100 Gb/s units: ch | used << 9 | free << 14 | cap << 19 | 1 << 31
+DEV uint32_t cs_pack(int ch, int used, int free_, int cap) {
+    return (uint32_t)ch | ((uint32_t)used << 9) | ((uint32_t)free_ << 14) | ((uint32_t)cap << 19) | 0x80000000u;
+}
+DEV int cs_ch(uint32_t e) { return (int)(e & 0x1ffu); }
+DEV int cs_used(uint32_t e) { return (int)((e >> 9) & 0x1fu); }
+DEV int cs_free(uint32_t e) { return (int)((e >> 14) & 0x1fu); }
+DEV int cs_cap(uint32_t e) { return (int)((e >> 19) & 0x1fu); }
 static_assert(sizeof(OrlgPhySvc) == 32, "OrlgPhySvc layout");
 
 // per-env scalars in HBM (256 B)
@@ -37,14 +47,15 @@ struct __attribute__((aligned(16))) OrlgPhyScalars {
 };
 static_assert(sizeof(OrlgPhyScalars) == 224, "OrlgPhyScalars layout");
 
-enum { ORLG_PHY_POLICY_EXT = -1, ORLG_PHY_POLICY_BMFA = 0, ORLG_PHY_POLICY_BMFA_RSS = 1 };
+// policies: ORLG_PHY_POLICY_* of include/orlg.h
 enum { ORLG_PHY_OUT_PATH = 0, ORLG_PHY_OUT_NCH, ORLG_PHY_OUT_CHANNELS, ORLG_PHY_OUT_ACCEPTED, ORLG_PHY_OUT_DONE,
        ORLG_PHY_OUT_REQUEST, ORLG_PHY_OUT_ARRIVAL, ORLG_PHY_OUT_HOLDING, ORLG_PHY_OUT_CUTS, ORLG_PHY_OUT_RSS,
-       ORLG_PHY_NUM_OUTS };
+       ORLG_PHY_OUT_CH_USED, ORLG_PHY_NUM_OUTS };
 
 struct OrlgPhyParams {
     int32_t B, N, E, C, K, NBR, Q, NW;
     int32_t episode_length, n_steps, policy, auto_reset, mode, out_mask, num_rows, cpad;
+    int32_t grooming, cs_len;
     double arrival_lambda, holding_lambda;
     // per-env state in HBM
     uint64_t *occ;          // [B][E*W]
@@ -52,15 +63,17 @@ struct OrlgPhyParams {
     OrlgPhySvc *qrec;       // [B][Q]
     uint32_t *mt;           // [B][624]
     OrlgPhyScalars *scal;   // [B]
+    uint32_t *cs;           // [B][N*N*K][cs_len] channel_state lists (virtual layer), list order = array order
+    uint8_t *cs_n;          // [B][N*N*K] list lengths
     // shared tables
     const unsigned char *tables;   // blob staged into LDS
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
-        t_plen;
+        t_plen, t_pathpair;
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
     const double *gsnr_t;   // [num_rows*K][cpad]
     // per-call IO
     const int32_t *act_path;      // external actions: [B] path (-2 = blocked)
-    const int16_t *act_channels;  // [B][ORLG_PHY_MAX_CH], -1 terminated
+    const int16_t *act_channels;  // [B][ORLG_PHY_MAX_CH], -1 terminated; channel | used << 9 (used 0 = the full capacity)
     void *outs[ORLG_PHY_NUM_OUTS];
     // per-wave LDS layout
     int32_t l_occ, l_qtime, l_mt, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
@@ -83,6 +96,7 @@ struct PhyTab {
     const uint16_t *adj;       // link | weight << 8
     const double *sqrt_tab;    // sqrt(k), k = 0..E*E
     const double *path_len;    // [num_paths]
+    const uint16_t *path_pair; // [num_paths] a * N + b of the pair (a < b) the record belongs to
     const uint64_t *outs;
 };
 
@@ -99,6 +113,7 @@ DEV PhyTab make_phy_tab(unsigned char *smem, const OrlgPhyParams &p) {
     tb.adj = reinterpret_cast<const uint16_t *>(smem + p.t_adj);
     tb.sqrt_tab = reinterpret_cast<const double *>(smem + p.t_sqrt);
     tb.path_len = reinterpret_cast<const double *>(smem + p.t_plen);
+    tb.path_pair = reinterpret_cast<const uint16_t *>(smem + p.t_pathpair);
     tb.outs = reinterpret_cast<const uint64_t *>(smem + p.l_outs);
     return tb;
 }
@@ -154,7 +169,7 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
 //   along the link axis, after taking the channel on the path's links minus before.
 template <int W>
 DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, int row, int lane,
-                         bool rss, int (&lv)[W], double (&mt)[W]) {
+                         int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W]) {
     const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
     const uint8_t *mrow = p.mod_t + (size_t)(row * p.K + idp) * p.cpad;
     // links of the path as a bit set (E <= 255: four words)
@@ -168,7 +183,9 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
             const bool fr = ((x >> lane) & 1ull) && ch < p.C;
             const int level = (int)mrow[ch];
             double metric;
-            if (!rss) {
+            if (metric_mode == 2) {
+                metric = 0.0;
+            } else if (metric_mode == 0) {
                 int m = 0;
                 for (int j = a0; j < a1; ++j) {
                     const unsigned aw = tb.adj[j];
@@ -199,7 +216,7 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
                 const double r1 = ORLG_FDIV(tb.sqrt_tab[sq1], (double)(sm1 + 1));
                 metric = r1 - r0;
             }
-            if (fr) { lv[w] = level; mt[w] = metric; }
+            if (fr) { lv[w] = flat_level ? 0 : level; mt[w] = metric; }
         }
     }
 }
@@ -233,6 +250,36 @@ DEV void phy_row_best(const int (&lv)[W], const double (&mt)[W], int lane, int &
     metric = M; channel = uni(Cc);
 }
 
+// ---- channel_state lists (virtual layer): one list = up to cs_len packed entries, entry i on lane i
+struct CsList { uint32_t e; int n, cap; };
+DEV CsList cs_load(const uint32_t *cs, const uint8_t *cs_n, int key, int lane, int cs_len) {
+    CsList l;
+    l.n = uni((int)cs_n[key]);
+    l.cap = cs_len;
+    l.e = lane < l.n ? cs[(size_t)key * cs_len + lane] : 0u;
+    return l;
+}
+DEV void cs_store(uint32_t *cs, uint8_t *cs_n, int key, const CsList &l, int lane) {
+    if (lane < l.n) cs[(size_t)key * l.cap + lane] = l.e;
+    if (lane == 0) cs_n[key] = (uint8_t)l.n;
+}
+DEV int cs_find(const CsList &l, int ch, int lane) {  // first entry with this channel number, -1 if none
+    u64 m = ballot(lane < l.n && cs_ch(l.e) == ch);
+    return m ? ctz64(m) : -1;
+}
+DEV uint32_t cs_get(const CsList &l, int q) { return (uint32_t)__builtin_amdgcn_readlane((int)l.e, q); }
+DEV void cs_remove(CsList &l, int q, int lane) {  // list.remove(entry q): later entries move up
+    uint32_t nxt = (uint32_t)__shfl_down((int)l.e, 1);
+    if (lane >= q) l.e = lane + 1 < l.n ? nxt : 0u;
+    l.n -= 1;
+}
+DEV bool cs_append(CsList &l, uint32_t v, int lane) {  // list.append
+    if (l.n >= l.cap) return false;
+    if (lane == l.n) l.e = v;
+    l.n += 1;
+    return true;
+}
+
 template <int W>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -255,13 +302,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     u64 *occ = reinterpret_cast<u64 *>(wb + p.l_occ);
     double *qtime = reinterpret_cast<double *>(wb + p.l_qtime);
     uint32_t *mt = reinterpret_cast<uint32_t *>(wb + p.l_mt);
-    uint32_t *scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);  // 3 KiB: scores / selection / rss terms
+    uint32_t *scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);  // selection lists + per-channel doubles
     PhyWaveScalars *ws = reinterpret_cast<PhyWaveScalars *>(wb + p.l_wsc);
     Wave wv;  // for draw5
     wv.lane = lane; wv.mt = mt;
 
     const int E = p.E, C = p.C, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     OrlgPhySvc *grec = p.qrec + (size_t)env * Q;
+    uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
+    uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
 
     // ------------------------------------------------------------------ HBM -> LDS
     const OrlgPhyScalars *gs = p.scal + env;
@@ -290,8 +339,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     wave_sync();
 
     int *sel_ch = reinterpret_cast<int *>(scratch);            // [16] selected channels
-    int *sel_mod = reinterpret_cast<int *>(scratch) + 16;      // [16] their modulation levels
-    unsigned *maxword = reinterpret_cast<unsigned *>(scratch) + 32;
+    int *sel_cap = reinterpret_cast<int *>(scratch) + 16;      // [16] their capacity (modulation level)
+    int *sel_used = reinterpret_cast<int *>(scratch) + 32;     // [16] the share this service uses
     double *scratch_d = reinterpret_cast<double *>(scratch + 64);  // [W*64] per-channel doubles
 
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
@@ -300,91 +349,161 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             const int base = tb.pair_base[req_src * N + req_dst];
             const int row = tb.pair_row[req_src * N + req_dst];
             const int demand = tb.bit_rates[req_br];
+            const int policy = p.policy;
             int a_path = -2, nsel = 0;
 
-            if (p.policy == ORLG_PHY_POLICY_EXT) {
+            if (policy == ORLG_PHY_POLICY_EXTERNAL) {
                 const OrlgPhyParams __attribute__((address_space(4))) *kp =
                     (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
                 a_path = uni(kp->act_path[env]);
                 const int16_t *ac = kp->act_channels + (size_t)env * ORLG_PHY_MAX_CH;
-                if (lane < ORLG_PHY_MAX_CH) {
-                    int c = ac[lane];
-                    sel_ch[lane] = c;
-                }
-                wave_sync();
-                u64 m = ballot(lane < ORLG_PHY_MAX_CH && sel_ch[lane] >= 0);
-                nsel = popc64(m);  // channels are the leading non-negative entries
-                if (a_path >= 0 && a_path < K && lane < nsel) {
-                    int c = sel_ch[lane];
-                    sel_mod[lane] = (c >= 0 && c < C) ? (int)p.mod_t[(size_t)(row * K + a_path) * p.cpad + c] : 0;
+                int raw = lane < ORLG_PHY_MAX_CH ? (int)ac[lane] : -1;
+                nsel = popc64(ballot(raw >= 0));  // channels are the leading non-negative entries
+                const int idp = a_path > 10 ? a_path - 20 : a_path;
+                if (lane < nsel) {
+                    const int c = raw & 0x1ff, u = (raw >> 9) & 0x1f;
+                    int cap = (idp >= 0 && idp < K && c < C) ? (int)p.mod_t[(size_t)(row * K + idp) * p.cpad + c] : 0;
+                    sel_ch[lane] = c; sel_cap[lane] = cap; sel_used[lane] = u ? u : cap;
                 }
                 wave_sync();
             } else {
-                // ---------------- phy_aware_bmfa_rmsa / phy_aware_bmfa_rss_rmsa (phy_rmsa_env.py:1375-1505), grooming off.
-                // Per path ("row") the free channels are ordered by (level desc, fragmentation metric desc, channel asc)
-                // = sorted(row, key=(-level, -metric)); the row with the best head (level, metric) is tried first,
-                // its channels are taken in order until the bit rate is covered, otherwise the row is dropped.
-                const bool rss = p.policy == ORLG_PHY_POLICY_BMFA_RSS;
-                const int pp = lane / W, pw = lane - pp * W;
-                const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-                // pass 1: head (level, metric) of every row
-                int head_level[ORLG_PHY_MAX_K];
-                double head_metric[ORLG_PHY_MAX_K];
-                unsigned alive = 0;
-#pragma unroll
-                for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
-                    head_level[idp] = -1; head_metric[idp] = 0.0;
-                    if (idp < K) {
-                        int lv[W];
-                        double mt[W];
-                        phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, row, lane, rss, lv, mt);
-                        int bl; double bm; int bc;
-                        phy_row_best<W>(lv, mt, lane, bl, bm, bc);
-                        if (bl >= 0) { head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp; }
-                    }
-                }
-                for (;;) {
-                    int best = -1, bl = -1;
-                    double bm = 0.0;
-#pragma unroll
-                    for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
-                        if (idp < K && ((alive >> idp) & 1u)) {
-                            // row[0][0] > max_level or (row[0][0] == max_level and row[0][1] > max_metric)
-                            if (best < 0 || head_level[idp] > bl || (head_level[idp] == bl && head_metric[idp] > bm)) {
-                                best = idp; bl = head_level[idp]; bm = head_metric[idp];
+                // ---------------- the heuristics of phy_rmsa_env.py:1254-1737
+                const bool with_metric = policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC;
+                const bool groom = with_metric ? (p.grooming != 0) : true;
+                bool served = false;
+                if (groom) {
+                    // use_existing_channels (:1650-1673): residual capacity on channels this (src, dst, k-path) already lights
+                    int unassigned = demand;
+                    for (int idp = 0; idp < K && !served; ++idp) {
+                        const CsList l = cs_load(gcs, gcs_n, (req_src * N + req_dst) * K + idp, lane, p.cs_len);
+                        int fr = lane < l.n ? cs_free(l.e) : 0;
+                        int sum = fr;
+                        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                        sum = uni(sum);
+                        if (sum * 100 >= unassigned) {
+                            for (int i = 0; i < l.n && nsel < ORLG_PHY_MAX_CH; ++i) {
+                                const uint32_t en = cs_get(l, i);
+                                const int f = cs_free(en);
+                                if (f > 0) {
+                                    unassigned -= f * 100;
+                                    int take = f;
+                                    if (unassigned <= 0) take = f + unassigned / 100;  // unassigned is a multiple of 100
+                                    if (lane == 0) { sel_ch[nsel] = cs_ch(en); sel_cap[nsel] = cs_cap(en); sel_used[nsel] = take; }
+                                    nsel += 1;
+                                    if (unassigned <= 0) { a_path = idp + 20; served = true; break; }
+                                }
                             }
                         }
-                    if (best < 0) break;
-                    // pass 2: the chosen row again, then greedy extraction in sorted order
-                    int lv[W];
-                    double mt[W];
-                    phy_row_metrics<W>(occ, tb, p, acc, best, base + best, row, lane, rss, lv, mt);
-                    int unassigned = demand;
-                    nsel = 0;
-                    bool covered = false;
-                    while (nsel < ORLG_PHY_MAX_CH) {
-                        int l0, c0;
-                        double m0;
-                        phy_row_best<W>(lv, mt, lane, l0, m0, c0);
-                        if (l0 < 0) break;
-#pragma unroll
-                        for (int w = 0; w < W; ++w)
-                            if (64 * w + lane == c0) lv[w] = -1;
-                        if (lane == 0) { sel_ch[nsel] = c0; sel_mod[nsel] = l0; }
-                        nsel += 1;
-                        unassigned -= l0 * 100;
-                        if (unassigned <= 0) { covered = true; break; }
                     }
-                    if (covered) { a_path = best; break; }
-                    alive &= ~(1u << best);  // sorted_free_channels.pop(row)
-                    nsel = 0;
+                    if (!served) nsel = 0;
+                }
+                if (!served) {
+                    // per path ("row") the free channels ordered by (level desc, metric desc, channel asc)
+                    //   bmfa / bmfa_rss: sorted(row, key=(-level, -metric)), row with the best head (level, metric)
+                    //   bmff:            sorted(row, key=(-level, channel)),  row with the best head level (ties: lower index)
+                    //   sapbm:           sorted(row, key=(-level, channel)),  first non-empty row
+                    //   sapff:           sorted(row, key=channel),            first non-empty row
+                    const int metric_mode = policy == ORLG_PHY_POLICY_BMFA_CUT ? 0 : policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC ? 1 : 2;
+                    const bool flat = policy == ORLG_PHY_POLICY_SAPFF;
+                    const bool first_row = policy == ORLG_PHY_POLICY_SAPFF || policy == ORLG_PHY_POLICY_SAPBM;
+                    const int pp = lane / W, pw = lane - pp * W;
+                    const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
+                    int head_level[ORLG_PHY_MAX_K];
+                    double head_metric[ORLG_PHY_MAX_K];
+                    unsigned alive = 0;
+#pragma unroll
+                    for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
+                        head_level[idp] = -1; head_metric[idp] = 0.0;
+                        if (idp < K) {
+                            int lv[W];
+                            double mtr[W];
+                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, row, lane, metric_mode, flat, lv, mtr);
+                            int bl, bc;
+                            double bm;
+                            phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
+                            if (bl >= 0) { head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp; }
+                        }
+                    }
+                    for (;;) {
+                        int best = -1, bl = -1;
+                        double bm = 0.0;
+#pragma unroll
+                        for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
+                            if (idp < K && ((alive >> idp) & 1u)) {
+                                if (best < 0 || (!first_row && (head_level[idp] > bl ||
+                                                                (with_metric && head_level[idp] == bl && head_metric[idp] > bm)))) {
+                                    best = idp; bl = head_level[idp]; bm = head_metric[idp];
+                                }
+                            }
+                        if (best < 0) break;
+                        int lv[W];
+                        double mtr[W];
+                        phy_row_metrics<W>(occ, tb, p, acc, best, base + best, row, lane, metric_mode, flat, lv, mtr);
+                        const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
+                        int unassigned = demand;
+                        nsel = 0;
+                        bool covered = false;
+                        while (nsel < ORLG_PHY_MAX_CH) {
+                            int l0, c0;
+                            double m0;
+                            phy_row_best<W>(lv, mtr, lane, l0, m0, c0);
+                            if (l0 < 0) break;
+#pragma unroll
+                            for (int w = 0; w < W; ++w)
+                                if (64 * w + lane == c0) lv[w] = -1;
+                            const int level = flat ? (int)mrow[c0] : l0;
+                            unassigned -= level * 100;
+                            const int used = unassigned <= 0 ? level + unassigned / 100 : level;
+                            if (lane == 0) { sel_ch[nsel] = c0; sel_cap[nsel] = level; sel_used[nsel] = used; }
+                            nsel += 1;
+                            if (unassigned <= 0) { covered = true; break; }
+                        }
+                        if (covered) { a_path = best; break; }
+                        alive &= ~(1u << best);  // sorted_free_channels.pop(row)
+                        nsel = 0;
+                    }
                 }
                 wave_sync();
             }
 
             // ========================================================== PhyRMSAEnv.step (phy_rmsa_env.py:272-351)
             bool accepted = false;
-            if (a_path >= 0 && a_path < K && nsel > 0) {
+            const bool dirbit = req_src > req_dst;
+            if (a_path > 10 && a_path - 20 < K && nsel > 0) {
+                // ---- virtual layer: _service_acceptance(True), _provision_virtual_path (:280-288, 625-659)
+                const int idp = a_path - 20, gid = base + idp;
+                const int key = (req_src * N + req_dst) * K + idp;
+                CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+                bool ok = true;
+                for (int ci = 0; ci < nsel && ok; ++ci) {
+                    const int q = cs_find(l, sel_ch[ci], lane);
+                    if (q < 0) { ok = false; break; }
+                    const uint32_t en = cs_get(l, q);
+                    const int take = sel_used[ci];
+                    if (cs_free(en) < take) { ok = false; break; }  // the reference raises here
+                    cs_remove(l, q, lane);
+                    cs_append(l, cs_pack(cs_ch(en), cs_used(en) + take, cs_free(en) - take, cs_cap(en)), lane);
+                }
+                if (ok) {
+                    cs_store(gcs, gcs_n, key, l, lane);
+                    if (lane == 0) { ws->c[1] += 1; ws->c[3] += 1; ws->c[5] += demand; ws->c[7] += demand; }
+                    accepted = true;
+                    if (n_running < Q) {
+                        if (lane == 0) {
+                            qtime[n_running] = ws->req_arrival + ws->req_holding;
+                            OrlgPhySvc sv;
+                            sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(1 | (dirbit ? 2 : 0));
+                            for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
+                                sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) | (1 << 14)) : 0xffffu;
+                            grec[n_running] = sv;
+                        }
+                        n_running += 1;
+                    } else if (lane == 0) {
+                        ws->q_overflow = 1;
+                    }
+                    wave_sync();
+                }
+            } else if (a_path >= 0 && a_path < K && nsel > 0) {
                 const int gid = base + a_path;
                 const OrlgPathRec *rec = tb.recs + gid;
                 const int hops = rec->hops;
@@ -406,12 +525,27 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                             rowp[ch >> 6] &= ~(1ull << (ch & 63));
                         }
                     }
+                    // partially used channels enter channel_state (:600-602)
+                    {
+                        const int key = (req_src * N + req_dst) * K + a_path;
+                        CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+                        bool changed = false, overflow = false;
+                        for (int ci = 0; ci < nsel; ++ci) {
+                            const int cap = sel_cap[ci], used = sel_used[ci];
+                            if (used != cap) {
+                                if (!cs_append(l, cs_pack(sel_ch[ci], used, cap - used, cap), lane)) overflow = true;
+                                changed = true;
+                            }
+                        }
+                        if (changed) cs_store(gcs, gcs_n, key, l, lane);
+                        if (overflow && lane == 0) ws->q_overflow = 1;
+                    }
                     // statistics, in channel order (the GSNR sum is a float64 accumulation)
                     if (lane == 0) {
                         const double *grow = p.gsnr_t + (size_t)(row * K + a_path) * p.cpad;
                         double tg = ws->total_gsnr;
                         long long tm = ws->total_mod;
-                        for (int ci = 0; ci < nsel; ++ci) { tg += grow[sel_ch[ci]]; tm += sel_mod[ci]; }
+                        for (int ci = 0; ci < nsel; ++ci) { tg += grow[sel_ch[ci]]; tm += sel_cap[ci]; }
                         ws->total_gsnr = tg; ws->total_mod = tm;
                         ws->channels_accepted += nsel;
                         // _service_acceptance(False) (:767-778)
@@ -426,8 +560,11 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         if (lane == 0) {
                             qtime[n_running] = ws->req_arrival + ws->req_holding;
                             OrlgPhySvc sv;
-                            sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.pad = 0;
-                            for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci) sv.ch[ci] = ci < nsel ? (uint16_t)sel_ch[ci] : 0xffffu;
+                            sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(dirbit ? 2 : 0);
+                            for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
+                                sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) |
+                                                                   ((sel_used[ci] != sel_cap[ci] ? 1 : 0) << 14))
+                                                      : 0xffffu;
                             grec[n_running] = sv;
                         }
                         n_running += 1;
@@ -448,6 +585,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                 if (om & (1 << ORLG_PHY_OUT_CHANNELS)) {
                     int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CHANNELS]) + o * ORLG_PHY_MAX_CH;
                     if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_ch[lane] : (int16_t)-1;
+                }
+                if (om & (1 << ORLG_PHY_OUT_CH_USED)) {
+                    int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CH_USED]) + o * ORLG_PHY_MAX_CH;
+                    if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_used[lane] : (int16_t)0;
                 }
                 if (lane == 0) {
                     if (om & (1 << ORLG_PHY_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_PATH])[o] = a_path;
@@ -495,23 +636,67 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                 ws->c[0] += 1; ws->c[2] += 1; ws->c[4] += br_val; ws->c[6] += br_val;
                 ws->req_arrival = at; ws->req_holding = ht;
             }
-            // ---- release every service with release time <= now (:1009-1017, _release_path :781-861 with grooming off).
-            // Channel frees commute, so the order of simultaneous releases is immaterial here.
-            for (int q0 = 0; q0 < n_running;) {
-                const int idx = q0 + lane;
-                double tq = idx < n_running ? qtime[idx] : __longlong_as_double((long long)ORLG_INF_BITS);
-                u64 m = ballot(tq <= current_time);
-                if (!m) { q0 += 64; continue; }
-                const int l = ctz64(m);
-                const int victim = q0 + l;
+            // ---- release every service with release time <= now in time order (:1009-1017, _release_path :781-861):
+            // with the virtual layer the order of simultaneous releases decides who frees a shared channel
+            for (;;) {
+                double best_t = 0.0;
+                int victim = -1;
+                for (int q0 = 0; q0 < n_running; q0 += 64) {
+                    const int idx = q0 + lane;
+                    double tq = idx < n_running ? qtime[idx] : __longlong_as_double((long long)ORLG_INF_BITS);
+                    u64 m = ballot(tq <= current_time);
+                    while (m) {
+                        const int l = ctz64(m);
+                        m &= m - 1;
+                        const double tt = readlane_d(tq, l);
+                        if (victim < 0 || tt < best_t) { best_t = tt; victim = q0 + l; }
+                    }
+                }
+                if (victim < 0) break;
                 const OrlgPhySvc sv = grec[victim];
                 const OrlgPathRec *rec = tb.recs + sv.gid;
+                const int pair = tb.path_pair[sv.gid];
+                const int pa = pair / N, pb = pair - pa * N;
+                const int ssrc = (sv.flags & 2) ? pb : pa, sdst = (sv.flags & 2) ? pa : pb;
+                const int idp = (int)sv.gid - tb.pair_base[pair];
+                const int key = (ssrc * N + sdst) * K + idp;
+                u64 freemask[W];  // channels to return on every link of the path
+#pragma unroll
+                for (int w = 0; w < W; ++w) freemask[w] = 0ull;
+                bool any_partial = false;
+                for (int ci = 0; ci < sv.nch; ++ci) {
+                    const int raw = sv.ch[ci];
+                    if (raw & (1 << 14)) { any_partial = true; } else {
+                        const int ch = raw & 0x1ff;
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                            if ((ch >> 6) == w) freemask[w] |= 1ull << (ch & 63);
+                    }
+                }
+                if (any_partial) {
+                    CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+                    for (int ci = 0; ci < sv.nch; ++ci) {
+                        const int raw = sv.ch[ci];
+                        if (!(raw & (1 << 14))) continue;
+                        const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
+                        const int q = cs_find(l, ch, lane);
+                        if (q < 0) continue;  // cannot happen for states produced by this kernel
+                        const uint32_t en = cs_get(l, q);
+                        cs_remove(l, q, lane);
+                        if (cs_used(en) == mine) {  // last user of the channel: it goes dark
+#pragma unroll
+                            for (int w = 0; w < W; ++w)
+                                if ((ch >> 6) == w) freemask[w] |= 1ull << (ch & 63);
+                        } else {
+                            cs_append(l, cs_pack(ch, cs_used(en) - mine, cs_free(en) + mine, cs_cap(en)), lane);
+                        }
+                    }
+                    cs_store(gcs, gcs_n, key, l, lane);
+                }
                 if (lane < rec->hops) {
                     u64 *rowp = occ + (int)rec->link[lane] * W;
-                    for (int ci = 0; ci < sv.nch; ++ci) {
-                        const int ch = sv.ch[ci];
-                        rowp[ch >> 6] |= 1ull << (ch & 63);
-                    }
+#pragma unroll
+                    for (int w = 0; w < W; ++w) rowp[w] |= freemask[w];
                 }
                 // swap-remove: the last live entry takes the victim's place
                 n_running -= 1;
@@ -520,7 +705,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                     grec[victim] = grec[n_running];
                 }
                 wave_sync();
-                // re-examine the same chunk (its slot `victim` now holds another service)
             }
         }
 

@@ -1,10 +1,13 @@
-"""BatchedPhyRMSAEnv: B independent QoT-aware environments (``PhyRMSAEnv``, ``phy_rmsa_env.py:20``), physical
-layer, on one MI355X.  Constructor kwargs are the reference's (``phy_rmsa_env.py:30-58``); ``modulation_level`` /
-``gsnr`` are the ``(pairs, channels, k)`` tables and ``connections_detail`` the table's (source, destination)
-node numbers per row (an ``[rows, 2]`` int array, or the reference's MATLAB object array).
+"""BatchedPhyRMSAEnv: B independent QoT-aware environments (``PhyRMSAEnv``, ``phy_rmsa_env.py:20``) on one
+MI355X: physical layer and virtual ("grooming") layer.  Constructor kwargs are the reference's
+(``phy_rmsa_env.py:30-58``); ``modulation_level`` / ``gsnr`` are the ``(pairs, channels, k)`` tables and
+``connections_detail`` the table's (source, destination) node numbers per row (an ``[rows, 2]`` int array, or the
+reference's MATLAB object array).
 
-Scope: ``grooming=False`` and no periodic defragmentation -- the reference's live experiment configuration
-(``tests/test_rmsa_threads_us.py:133-148``).  ``grooming=True`` / ``defrag_period`` raise NotImplementedError.
+Device policies (``run(policy, ...)``): ``bmfa`` / ``bmfa_rss`` (``phy_rmsa_env.py:1375,1441``; they consult the
+virtual layer only when ``grooming=True``), ``sapff`` / ``bmff`` / ``sapbm`` (``:1676,1317,1254``; they always try
+``use_existing_channels`` first, like the reference) and ``external``.  Not built: the periodic defragmentation
+(``defrag_period`` raises NotImplementedError).
 """
 from __future__ import annotations
 
@@ -32,6 +35,18 @@ def _pairs_from_connections_detail(cd):
     return np.ascontiguousarray(cd[:, :2], dtype=np.int32)
 
 
+def encode_channels(selected_channels, out_row):
+    """The reference's ``selected_channels`` tuples ``(channel, used, free, capacity, virtual)`` (``phy_rmsa_env.py:
+    1364-1366``) -> one ``act_channels`` row: channel | used << 9 (``used`` in 100 Gb/s units; bare ints = whole channel)."""
+    out_row[:] = -1
+    for q, c in enumerate(selected_channels):
+        if isinstance(c, (tuple, list, np.ndarray)):
+            out_row[q] = int(c[0]) | (int(round(float(c[1]))) << 9 if len(c) > 1 else 0)
+        else:
+            out_row[q] = int(c)
+    return out_row
+
+
 class BatchedPhyRMSAEnv:
     def __init__(self, topology, batch_size: int, *, modulation_level, connections_detail, gsnr,
                  episode_length: int = 1000, load: float = 10, mean_service_holding_time: float = 10800.0,
@@ -40,9 +55,7 @@ class BatchedPhyRMSAEnv:
                  allow_rejection: bool = False, number_spectrum_channels: int = 80,
                  number_spectrum_channels_s_band: int = 108, l_band: bool = True, s_band: bool = True,
                  defrag_period=None, number_moves=None, metric: str = "cut", grooming: bool = False,
-                 queue_capacity: int = 0, device: int = 0, **_ignored):
-        if grooming:
-            raise NotImplementedError("the virtual (grooming) layer is not on the device path yet")
+                 queue_capacity: int = 0, channel_state_capacity: int = 0, device: int = 0, **_ignored):
         if defrag_period:
             raise NotImplementedError("periodic defragmentation is not on the device path yet")
         self.L = _lib.load()
@@ -89,6 +102,8 @@ class BatchedPhyRMSAEnv:
         cc = _lib.PhyConfig()
         cc.num_channels, cc.episode_length, cc.num_bit_rates = self.num_channels, self.episode_length, len(self.bit_rates)
         cc.k_table, cc.num_table_rows, cc.queue_capacity = mod.shape[2], mod.shape[0], int(queue_capacity)
+        cc.grooming, cc.channel_state_capacity = (1 if grooming else 0), int(channel_state_capacity)
+        self.grooming = bool(grooming)
         cc.arrival_lambda = 1 / self.mean_service_inter_arrival_time
         cc.holding_lambda = 1 / self.mean_service_holding_time
         cc.bit_rates = keep(self.bit_rates, np.int32)
@@ -131,13 +146,15 @@ class BatchedPhyRMSAEnv:
 
     def run(self, policy: str, n_steps: int = 1, *, act_path=None, act_channels=None, auto_reset: bool = False,
             outputs: Sequence[str] = ()):
-        """``n_steps`` x (policy -> PhyRMSAEnv.step).  ``policy='external'``: ``act_path`` [B] int32 (-2 = blocked)
-        and ``act_channels`` [B, 14] int16 (-1 padded).  Returns the requested per-step arrays [n_steps, B(, ...)]."""
+        """``n_steps`` x (policy -> PhyRMSAEnv.step).  ``policy='external'``: ``act_path`` [B] int32 (-2 = blocked,
+        0..k-1 physical, 20 + k-path virtual layer) and ``act_channels`` [B, 14] int16 (-1 padded; entry = channel |
+        used << 9, see :func:`encode_channels`).  Returns the requested per-step arrays [n_steps, B(, ...)]."""
         B = self.batch_size
         io = _lib.PhyStepIO()
         res = {}
         for name in outputs:
-            shape = {"request": (n_steps, B, 4), "channels": (n_steps, B, _lib.PHY_MAX_CHANNELS)}.get(name, (n_steps, B))
+            shape = {"request": (n_steps, B, 4), "channels": (n_steps, B, _lib.PHY_MAX_CHANNELS),
+                     "channels_used": (n_steps, B, _lib.PHY_MAX_CHANNELS)}.get(name, (n_steps, B))
             res[name] = np.zeros(shape, dtype=_lib.PHY_STEP_IO_DTYPES[name])
             setattr(io, name, _ptr(res[name]))
         ap = ac = None
@@ -192,6 +209,25 @@ class BatchedPhyRMSAEnv:
         _lib.check(self.L.orlg_phy_get_occupancy(self.h, _ptr(w)))
         bits = np.unpackbits(w.view(np.uint8), axis=-1, bitorder="little")
         return bits.reshape(self.batch_size, E, -1)[:, :, :self.num_channels]
+
+    def channel_state(self, env_index: int = 0):
+        """``env.channel_state`` of one env (``phy_rmsa_env.py:117-125``): dict (src_id, dst_id, k-path) -> list of
+        (channel, used, free, capacity) tuples in list order (100 Gb/s units); empty lists are omitted."""
+        t = self.topology
+        lists = t.num_nodes * t.num_nodes * t.k_paths
+        cap = self.L.orlg_phy_channel_state_capacity(self.h)
+        ent = np.zeros((lists, cap), np.uint32)
+        n = np.zeros(lists, np.uint8)
+        rc = self.L.orlg_phy_get_channel_state(self.h, int(env_index), _ptr(ent), _ptr(n))
+        if rc < 0:
+            _lib.check(rc)
+        out = {}
+        for key in np.nonzero(n)[0]:
+            e = ent[key, :n[key]].astype(np.int64)
+            s, rem = divmod(int(key), t.num_nodes * t.k_paths)
+            d, k = divmod(rem, t.k_paths)
+            out[(s, d, k)] = [(int(x & 0x1ff), int((x >> 9) & 0x1f), int((x >> 14) & 0x1f), int((x >> 19) & 0x1f)) for x in e]
+        return out
 
     def reduce_counters(self):
         a = np.zeros(16, np.int64)

@@ -1,13 +1,13 @@
 """Single-environment view of the QoT-aware environment with the reference's object surface.
 
-``PhyRMSAEnv`` is a drop-in for ``optical_rl_gym.envs.phy_rmsa_env.PhyRMSAEnv`` (physical layer:
-``grooming=False``, no periodic defragmentation): same constructor kwargs, ``step((path, channels))`` returning the
-reference's 5-tuple ``(obs, reward, done, False, info)`` with the same info keys (``phy_rmsa_env.py:319-348``), and the
-attributes / query methods its heuristic callbacks touch (``phy_rmsa_env.py:1375-1438``): ``is_channel_free``,
-``calculate_r_cut``, ``calculate_r_spatial``, ``modulation_level``, ``connections_detail``, ``k_shortest_paths``,
-``topology[a][b]["index"]``, ``topology.graph["num_channel_resources"]``, ``current_service``.
+``PhyRMSAEnv`` is a drop-in for ``optical_rl_gym.envs.phy_rmsa_env.PhyRMSAEnv`` (physical and virtual layer, no
+periodic defragmentation): same constructor kwargs, ``step((path, channels))`` returning the reference's 5-tuple
+``(obs, reward, done, False, info)`` with the same info keys (``phy_rmsa_env.py:319-348``), and the attributes / query
+methods its heuristic callbacks touch (``phy_rmsa_env.py:1254-1737``): ``is_channel_free``, ``calculate_r_cut``,
+``calculate_r_spatial``, ``modulation_level``, ``connections_detail``, ``k_shortest_paths``, ``channel_state``,
+``grooming``, ``topology[a][b]["index"]``, ``topology.graph["num_channel_resources"]``, ``current_service``.
 The environment lives on the GPU (a :class:`BatchedPhyRMSAEnv` of batch 1); queries read device state through the C
-ABI.  ``phy_aware_bmfa_rmsa`` below is this package's statement of the reference heuristic on that surface.
+ABI.  The heuristics at the bottom are this package's statements of the reference's callbacks on that surface.
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from .envs import RMSAEnv as _RMSAView
-from .phy import PHY_DEFAULT_BIT_RATES, BatchedPhyRMSAEnv
+from .phy import PHY_DEFAULT_BIT_RATES, BatchedPhyRMSAEnv, encode_channels
 from .topology import Path, Service
 
 
@@ -30,6 +30,18 @@ class _PhyGraph(dict):
         if key == "available_channels":
             return self._env._available()
         return super().__getitem__(key)
+
+
+class _ChannelState:
+    """``env.channel_state[src_id, dst_id, k-path]`` (``phy_rmsa_env.py:117-125``): the list of (channel, used, free,
+    capacity) tuples of partially used channels, read from the device on first use after every step."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getitem__(self, key):
+        s, d, k = (int(x) for x in key)
+        return list(self._env._channel_lists().get((s, d, k), []))
 
 
 class PhyRMSAEnv:
@@ -71,12 +83,8 @@ class PhyRMSAEnv:
         self.number_spectrum_channels_s_band = number_spectrum_channels_s_band
         self.allow_rejection = allow_rejection
         self.bit_rates = list(b.bit_rates)
-        # grooming bookkeeping of the reference (always empty with grooming off)
-        self.channel_state = np.empty((ft.num_nodes, ft.num_nodes, ft.k_paths), dtype=object)
-        for i in range(ft.num_nodes):
-            for j in range(ft.num_nodes):
-                for k in range(ft.k_paths):
-                    self.channel_state[i, j, k] = []
+        self.channel_state = _ChannelState(self)
+        self.services_accepted_virtual = 0
         self.current_service: Optional[Service] = None
         self._sync()
 
@@ -92,6 +100,12 @@ class PhyRMSAEnv:
             setattr(self, name, int(arr[0]))
         self.current_time = float(b.current_time()[0])
         self._avail = None
+        self._cs = None
+
+    def _channel_lists(self):
+        if self._cs is None:
+            self._cs = self._batched.channel_state(0)
+        return self._cs
 
     def _available(self):
         if self._avail is None:
@@ -168,13 +182,12 @@ class PhyRMSAEnv:
     def step(self, action):
         """``phy_rmsa_env.py:272-424`` -> (observation, reward, done, False, info)"""
         path, channels = action[0], action[1]
-        if path > 10:
-            raise NotImplementedError("virtual-layer (grooming) actions are not on the device path yet")
         served = self.current_service
         ap = np.array([path], np.int32)
         ac = np.full((1, _lib.PHY_MAX_CHANNELS), -1, np.int16)
-        for q, c in enumerate(channels):
-            ac[0, q] = int(c[0])
+        encode_channels(channels, ac[0])
+        if path > 10:
+            self.services_accepted_virtual += 1
         r = self._batched.run("external", 1, act_path=ap, act_channels=ac,
                               outputs=("accepted", "done", "number_cuts_total", "rss_total_metric"))
         served.accepted = bool(r["accepted"][0, 0])
@@ -220,10 +233,125 @@ def _table_id(env) -> int:
     return int(np.where(((a == s) & (b == d)) | ((a == d) & (b == s)))[0][0])
 
 
+def use_existing_channels(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1650-1673``: serve the request from residual capacity of channels already lit between the same
+    (source, destination) on k-path idp; ``(-3, [])`` when no path's list covers the bit rate.  Like the reference the
+    running remainder is NOT restarted when a path's list turns out not to cover it."""
+    sv = env.current_service
+    unassigned, selected = sv.bit_rate, []
+    for idp in range(len(env.k_shortest_paths[sv.source, sv.destination])):
+        state = env.channel_state[sv.source_id, sv.destination_id, idp]
+        if sum(c[2] for c in state) >= unassigned / 100:
+            for ch, _used, free, cap in state:
+                if free > 0:
+                    unassigned -= free * 100
+                    if unassigned <= 0:
+                        selected.append((ch, free + unassigned / 100, unassigned / -100, cap, True))
+                        return (idp, selected)
+                    selected.append((ch, free, 0, cap, True))
+    return (-3, [])
+
+
+def _free_channel_rows(env, metric=None):
+    """Per candidate path the free channels as (level, metric, channel, idp) in channel order."""
+    table_id = _table_id(env)
+    rows = []
+    for idp, path in enumerate(env.k_shortest_paths[env.current_service.source, env.current_service.destination]):
+        links = [env.topology[path.node_list[i]][path.node_list[i + 1]]["index"] for i in range(len(path.node_list) - 1)]
+        row = []
+        for ch in range(env.topology.graph["num_channel_resources"]):
+            if env.is_channel_free(path, ch):
+                level = int(env.modulation_level[table_id][ch][idp])
+                m = 0 if metric is None else metric(env, ch, links, path)
+                row.append((level, m, ch, idp))
+        rows.append(row)
+    return rows
+
+
+def _take_channels(env, rows, pick):
+    """Greedy cover of the bit rate from the row ``pick`` selects; a row that cannot cover it is dropped."""
+    rows = [r for r in rows]
+    while True:
+        rows = [r for r in rows if r]
+        best = pick(rows)
+        if best is None:
+            return (-2, [])
+        unassigned, selected = env.current_service.bit_rate, []
+        for level, _, ch, idp in rows[best]:
+            unassigned -= level * 100
+            if unassigned <= 0:
+                selected.append((ch, level + unassigned / 100, unassigned / -100, level, False))
+                return (idp, selected)
+            selected.append((ch, level, 0, level, False))
+        rows.pop(best)
+
+
+def _with_virtual_layer(env, always):
+    if always or env.grooming:
+        idp, chans = use_existing_channels(env)
+        if idp != -3:
+            return (idp + 20, chans)
+    return None
+
+
+def sapff_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1676-1737``: virtual layer first, then the first path with a free channel, channels in index order."""
+    v = _with_virtual_layer(env, True)
+    if v:
+        return v
+    return _take_channels(env, _free_channel_rows(env), lambda rows: 0 if rows else None)
+
+
+def phy_aware_sapbm_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1254-1314``: virtual layer first, then the first path with a free channel, best modulation first."""
+    v = _with_virtual_layer(env, True)
+    if v:
+        return v
+    rows = [sorted(r, key=lambda x: (-x[0], x[2])) for r in _free_channel_rows(env)]
+    return _take_channels(env, rows, lambda rows: 0 if rows else None)
+
+
+def phy_aware_bmff_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1317-1372``: virtual layer first, then the path whose best free channel has the highest
+    modulation level (ties: the earlier path), channels by (level desc, index)."""
+    v = _with_virtual_layer(env, True)
+    if v:
+        return v
+    rows = [sorted(r, key=lambda x: (-x[0], x[2])) for r in _free_channel_rows(env)]
+
+    def pick(rows):
+        best, head = None, float("-inf")
+        for i, row in enumerate(rows):
+            if row[0][0] > head:
+                best, head = i, row[0][0]
+        return best
+    return _take_channels(env, rows, pick)
+
+
+def _pick_level_metric(rows):
+    best, head = None, (float("-inf"), float("-inf"))
+    for i, row in enumerate(rows):
+        if (row[0][0], row[0][1]) > head:
+            best, head = i, (row[0][0], row[0][1])
+    return best
+
+
+def phy_aware_bmfa_rss_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1441-1505``: as bmfa with the RSS metric (``calculate_r_spatial``)."""
+    v = _with_virtual_layer(env, False)
+    if v:
+        return v
+    rows = _free_channel_rows(env, lambda e, ch, links, path: e.calculate_r_spatial(ch, links, False))
+    return _take_channels(env, [sorted(r, key=lambda x: (-x[0], -x[1])) for r in rows], _pick_level_metric)
+
+
 def phy_aware_bmfa_rmsa(env) -> Tuple[int, list]:
     """Best-modulation, fragmentation-aware (cut metric) channel selection, ``phy_rmsa_env.py:1375-1438`` with
-    grooming off: per path the free channels sorted by (level desc, cut metric desc); the row with the best head
-    wins; channels are taken in order until the bit rate is covered (the last one partially)."""
+    the virtual layer first when ``env.grooming``: per path the free channels sorted by (level desc, cut metric desc);
+    the row with the best head wins; channels are taken in order until the bit rate is covered (the last one partially)."""
+    v = _with_virtual_layer(env, False)
+    if v:
+        return v
     table_id = _table_id(env)
     rows = []
     for idp, path in enumerate(env.k_shortest_paths[env.current_service.source, env.current_service.destination]):

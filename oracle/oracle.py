@@ -334,13 +334,14 @@ def _phy_lib(asan=False):
         L.orc_phy_current_time.argtypes = [C.c_void_p]
         L.orc_phy_get_available_channels.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phy_num_running.argtypes = [C.c_void_p]
+        L.orc_phy_channel_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_phy_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(PhyTrace)]
         L._phy_ready = True
     return L
 
 
 class PhyOracleEnv:
-    """One reference-semantics PhyRMSAEnv (physical layer, grooming off) on the CPU."""
+    """One reference-semantics PhyRMSAEnv (physical + virtual layer, no periodic defragmentation) on the CPU."""
 
     def __init__(self, tables, *, num_channels, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
                  arrival_lambda, holding_lambda, pair_table_row, modulation_level, gsnr, link_ends, path_node_off,
@@ -423,6 +424,19 @@ class PhyOracleEnv:
 
     def num_running(self):
         return self.L.orc_phy_num_running(self.h)
+
+    def channel_state(self):
+        """env.channel_state as {(src_id, dst_id, k-path): [(channel, used, free, capacity), ...]}, empty lists omitted."""
+        out = {}
+        buf = np.zeros((256, 4), np.int32)
+        N, K = self._t.num_nodes, self._t.k_paths
+        for s in range(N):
+            for d in range(N):
+                for k in range(K):
+                    n = self.L.orc_phy_channel_state(self.h, s, d, k, _ptr(buf), 256)
+                    if n:
+                        out[(s, d, k)] = [tuple(int(x) for x in row) for row in buf[:n]]
+        return out
 
     def run(self, policy, n_steps, reset_on_done=False, fields=None):
         tr = PhyTrace()

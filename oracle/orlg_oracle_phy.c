@@ -524,6 +524,14 @@ void orc_phy_get_counters(const orc_phy_env *e, orc_counters *out) { *out = e->c
 double orc_phy_current_time(const orc_phy_env *e) { return e->current_time; }
 void orc_phy_get_available_channels(const orc_phy_env *e, uint8_t *out) { memcpy(out, e->avail, (size_t)e->E * e->C); }
 int orc_phy_num_running(const orc_phy_env *e) { return e->n_running; }
+/* channel_state[src, dst, idp] as (channel, used, free, capacity) rows in list order; returns the list length */
+int orc_phy_channel_state(orc_phy_env *e, int src, int dst, int idp, int32_t *out, int max_entries) {
+    const cs_list *l = cs_of(e, src, dst, idp);
+    for (int i = 0; i < l->n && i < max_entries; i++) {
+        out[4 * i] = l->e[i].ch; out[4 * i + 1] = l->e[i].used; out[4 * i + 2] = l->e[i].free_; out[4 * i + 3] = l->e[i].cap;
+    }
+    return l->n;
+}
 
 void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done, orc_phy_trace *tr) {
     orc_phy_action act;

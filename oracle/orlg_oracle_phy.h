@@ -71,6 +71,7 @@ void orc_phy_get_counters(const orc_phy_env *e, orc_counters *out);
 double orc_phy_current_time(const orc_phy_env *e);
 void orc_phy_get_available_channels(const orc_phy_env *e, uint8_t *out);
 int orc_phy_num_running(const orc_phy_env *e);
+int orc_phy_channel_state(orc_phy_env *e, int src, int dst, int idp, int32_t *out /* [max_entries][4] */, int max_entries);
 void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done, orc_phy_trace *tr);
 
 #ifdef __cplusplus

@@ -483,12 +483,19 @@ PHY_CASES = [
     ("phy_us14_s10_sapff", "us14_k3", dict(), "sapff", 600, True),
     ("phy_us14_s10_bmff", "us14_k3", dict(), "bmff", 600, True),
     ("phy_us14_s10_sapbm", "us14_k3", dict(), "sapbm", 600, True),
+    # env.grooming=True: bmfa / bmfa_rss consult the virtual layer too (phy_rmsa_env.py:1377-1380, 1443-1446)
+    ("phy_us14_s10_bmfa_groom", "us14_k3", dict(grooming=True), "bmfa", 800, True),
+    ("phy_us14_s13_bmfa_rss_groom_load3000", "us14_k3", dict(seed=13, load=3000, grooming=True), "bmfa_rss", 1200, True),
+    ("phy_us14_s14_sapff_load4000", "us14_k3", dict(seed=14, load=4000), "sapff", 2600, True),  # reaches blocking
+    ("phy_jpn12_s5_bmff", "jpn12_k3", dict(seed=5, load=900), "bmff", 800, True),
 ]
 
 
-def gen_phy():
+def gen_phy(only_missing=False):
     gen_phy_tables()
     for name, tab, over, policy, steps, reset in PHY_CASES:
+        if only_missing and os.path.exists(os.path.join(HERE, name + ".npz")):
+            continue
         kw = dict(PHY_BASE)
         kw.update(over)
         topo = load_pickled_topology(TOPOLOGIES[PHY_TABLES[tab][2]])
@@ -503,6 +510,11 @@ def gen_phy():
 
 
 # --------------------------------------------------------------------------- GN-model OSNR grid
+def gen_phy_new():
+    """Only the PhyRMSA cases whose fixture is not there yet."""
+    gen_phy(only_missing=True)
+
+
 def gen_osnr():
     """examples/calculate_osnr.py cannot be imported (it imports names that do not exist), has no caller
     and no test.  Its function body is self-contained arithmetic on duck-typed objects: the function text is executed

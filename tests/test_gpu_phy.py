@@ -8,7 +8,7 @@ from conftest import load_golden, load_phy_tables, load_topology, phy_oracle_fro
 from test_gpu_rmsa import device_log_in_oracle  # noqa: F401
 
 pytestmark = pytest.mark.gpu
-OUTS = ("act_path", "n_channels", "channels", "accepted", "done", "request", "arrival", "holding",
+OUTS = ("act_path", "n_channels", "channels", "channels_used", "accepted", "done", "request", "arrival", "holding",
         "number_cuts_total", "rss_total_metric")
 
 
@@ -20,14 +20,19 @@ def make_env(topo, tables, kw, batch, **extra):
 
 
 @pytest.mark.parametrize("case,nmax", [("phy_us14_s10_bmfa", 800), ("phy_jpn12_s3_bmfa", 500),
-                                       ("phy_us14_s12_bmfa_load4000", 2600), ("phy_us14_s10_bmfa_rss", 600)])
-def test_phy_bmfa_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
+                                       ("phy_us14_s12_bmfa_load4000", 2600), ("phy_us14_s10_bmfa_rss", 600),
+                                       ("phy_us14_s10_sapff", 800), ("phy_us14_s10_bmff", 800),
+                                       ("phy_us14_s10_sapbm", 800), ("phy_us14_s11_bmfa_load2400", 1500),
+                                       ("phy_us14_s10_bmfa_groom", 800), ("phy_us14_s13_bmfa_rss_groom_load3000", 1200),
+                                       ("phy_us14_s14_sapff_load4000", 2600), ("phy_jpn12_s5_bmff", 800)])
+def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     z, meta = load_golden(case)
     topo = load_topology(meta["topology"])
     tables = load_phy_tables(meta["tables"])
     kw = meta["env_kwargs"]
     n, batch = min(nmax, meta["steps"]), 4
     env = make_env(topo, tables, kw, batch)
+    assert env.grooming == kw.get("grooming", False)
     policy = meta["policy"]
     tr = env.run(policy, n, outputs=OUTS, auto_reset=True)
     cnt, now, nrun, av, est = env.counters(), env.current_time(), env.num_running(), env.available_channels(), env.episode_stats()
@@ -37,6 +42,7 @@ def test_phy_bmfa_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
         assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
         assert np.array_equal(tr["n_channels"][:, i], ot["n_channels"]), i
         assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["channels_used"][:, i, :12].astype(np.float64), ot["ch_used"]), i
         assert np.array_equal(tr["accepted"][:, i], ot["accepted"]) and np.array_equal(tr["done"][:, i], ot["done"])
         assert np.array_equal(tr["request"][:, i, 1], ot["src"]) and np.array_equal(tr["request"][:, i, 3], ot["bit_rate"])
         for f in ("arrival", "holding", "number_cuts_total", "rss_total_metric"):
@@ -50,10 +56,12 @@ def test_phy_bmfa_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
         # per-episode sums behind the info dict (the run ended right after an optional reset)
         assert est["physical_services_accepted"][i] == ot["physical_paths"][-1] or ot["done"][-1]
         assert est["queue_overflow"][i] == 0
+        assert env.channel_state(i) == o.channel_state(), i
         o.close()
     # env 0 is the reference's own trace
     assert np.array_equal(tr["act_path"][:, 0], z["act_path"][:n])
     assert np.array_equal(tr["channels"][:, 0, :12], z["channels"][:n])
+    assert np.array_equal(tr["channels_used"][:, 0, :12].astype(np.float64), z["ch_used"][:n])
     assert np.array_equal(tr["accepted"][:, 0], z["accepted"][:n])
     np.testing.assert_allclose(tr["arrival"][:, 0], z["arrival"][:n], rtol=1e-12)
     assert np.array_equal(tr["number_cuts_total"][:, 0], z["number_cuts_total"][:n])
@@ -104,7 +112,7 @@ def test_phy_external_actions(device_log_in_oracle):
                 a.ch[0] = int(rng.integers(0, 3))
             paths[i] = a.path
             for q in range(a.n):
-                chans[i, q] = a.ch[q]
+                chans[i, q] = a.ch[q] | (int(a.used[q]) << 9)
             acts.append(a)
         r = env.run("external", 1, act_path=paths, act_channels=chans, outputs=("accepted", "arrival"))
         for i, o in enumerate(oracles):
@@ -115,6 +123,42 @@ def test_phy_external_actions(device_log_in_oracle):
     av = env.available_channels()
     for i, o in enumerate(oracles):
         assert np.array_equal(av[i], o.available_channels())
+        o.close()
+    env.close()
+
+
+def test_phy_external_virtual_layer_actions(device_log_in_oracle):
+    """External actions incl. the virtual layer (path = 20 + k-path, per-channel shares): replay the oracle's sapff."""
+    z, meta = load_golden("phy_us14_s10_sapff")
+    topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
+    kw = meta["env_kwargs"]
+    env = make_env(topo, tables, kw, 2)
+    oracles = [phy_oracle_from_kwargs(topo, tables, kw, seed=kw["seed"] + i) for i in range(2)]
+    nvirt = 0
+    for t in range(400):
+        paths = np.full(2, -2, np.int32)
+        chans = np.full((2, 14), -1, np.int16)
+        acts = []
+        for i, o in enumerate(oracles):
+            a = o.policy("sapff")
+            paths[i] = a.path
+            nvirt += a.path > 10
+            for q in range(a.n):
+                chans[i, q] = a.ch[q] | (int(a.used[q]) << 9)
+            acts.append(a)
+        r = env.run("external", 1, act_path=paths, act_channels=chans, outputs=("accepted", "done"))
+        for i, o in enumerate(oracles):
+            res = o.step(acts[i])
+            assert r["accepted"][0, i] == res.accepted, (t, i)
+            if res.done:
+                o.reset()
+        if r["done"][0, 0]:
+            env.reset()
+    assert nvirt > 50
+    av = env.available_channels()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(av[i], o.available_channels())
+        assert env.channel_state(i) == o.channel_state()
         o.close()
     env.close()
 

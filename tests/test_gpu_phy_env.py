@@ -31,3 +31,31 @@ def test_phy_view_bmfa_matches_reference():
         assert info["episode_service_blocking_rate"] == z["episode_service_blocking_rate"][t]
         assert info["bit_rate_blocking_rate"] == z["bit_rate_blocking_rate"][t]
     env.close()
+
+
+@pytest.mark.parametrize("case,heuristic,n", [("phy_us14_s10_sapff", "sapff_rmsa", 260), ("phy_us14_s10_bmff", "phy_aware_bmff_rmsa", 120),
+                                              ("phy_us14_s10_sapbm", "phy_aware_sapbm_rmsa", 120),
+                                              ("phy_us14_s10_bmfa_groom", "phy_aware_bmfa_rmsa", 120),
+                                              ("phy_us14_s10_bmfa_rss", "phy_aware_bmfa_rss_rmsa", 60)])
+def test_phy_view_heuristics_with_virtual_layer(case, heuristic, n):
+    """The heuristic callbacks on the single-env view (incl. use_existing_channels on env.channel_state and virtual-layer
+    actions path = 20 + k-path) reproduce the reference's trace."""
+    import optical_rl_gym_amd as pkg
+    z, meta = load_golden(case)
+    pairs, mod, gsnr = load_phy_tables(meta["tables"])
+    env = pkg.PhyRMSAEnv(topology=load_topology(meta["topology"]), modulation_level=mod, connections_detail=pairs,
+                         gsnr=gsnr, **meta["env_kwargs"])
+    fn = getattr(pkg, heuristic)
+    for t in range(n):
+        a = fn(env)
+        assert a[0] == z["act_path"][t] and len(a[1]) == z["n_channels"][t], t
+        assert [c[0] for c in a[1]] == z["channels"][t][:len(a[1])].tolist()
+        assert [c[1] for c in a[1]] == z["ch_used"][t][:len(a[1])].tolist()
+        assert [c[2] for c in a[1]] == z["ch_free"][t][:len(a[1])].tolist()
+        obs, reward, done, truncated, info = env.step(a)
+        assert reward == z["reward"][t] and done == bool(z["done"][t])
+        assert info["number_cuts_total"] == z["number_cuts_total"][t]
+        assert info["physical_paths"] == z["physical_paths"][t]
+        if done:
+            env.reset()
+    env.close()

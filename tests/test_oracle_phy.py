@@ -1,4 +1,4 @@
-"""Oracle PhyRMSAEnv (physical layer, grooming off) against golden traces of the reference: bit-exact."""
+"""Oracle PhyRMSAEnv (physical + virtual layer) against golden traces of the reference: bit-exact."""
 import glob
 import os
 
