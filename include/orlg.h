@@ -221,6 +221,8 @@ enum {
     ORLG_PHY_POLICY_SAPFF = 2,     /* sapff_rmsa (phy_rmsa_env.py:1676-1737) */
     ORLG_PHY_POLICY_BMFF = 3,      /* phy_aware_bmff_rmsa (phy_rmsa_env.py:1317-1372) */
     ORLG_PHY_POLICY_SAPBM = 4,     /* phy_aware_sapbm_rmsa (phy_rmsa_env.py:1254-1314) */
+    ORLG_PHY_POLICY_FAFF = 5,      /* phy_aware_faff_rmsa (phy_rmsa_env.py:1508-1569), cut metric */
+    ORLG_PHY_POLICY_FAFF_RSS = 6,  /* phy_aware_faff_rss_rmsa (phy_rmsa_env.py:1572-1647), RSS metric */
 };
 #define ORLG_PHY_MAX_CHANNELS 14 /* channels per service */
 

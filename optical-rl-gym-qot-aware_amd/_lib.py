@@ -68,7 +68,7 @@ PHY_MAX_CHANNELS = 14
 PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
                       "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
                       "number_cuts_total": "float64", "rss_total_metric": "float64", "channels_used": "int16"}
-PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4}
+PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff": 5, "faff_rss": 6}
 
 _lib = None
 

@@ -384,7 +384,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
                   int32_t auto_reset, const orlg_phy_step_io *io) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     if (n_steps < 1) return fail(ORLG_ERR_INVALID, "n_steps must be >= 1");
-    if (policy < ORLG_PHY_POLICY_EXTERNAL || policy > ORLG_PHY_POLICY_SAPBM) return fail(ORLG_ERR_INVALID, "unknown PhyRMSA policy %d", policy);
+    if (policy < ORLG_PHY_POLICY_EXTERNAL || policy > ORLG_PHY_POLICY_FAFF_RSS) return fail(ORLG_ERR_INVALID, "unknown PhyRMSA policy %d", policy);
     if (policy == ORLG_PHY_POLICY_EXTERNAL && (!act_path || !act_channels || n_steps != 1))
         return fail(ORLG_ERR_INVALID, "external actions need path and channel arrays and n_steps == 1");
     HIP_TRY(hipSetDevice(e->device));

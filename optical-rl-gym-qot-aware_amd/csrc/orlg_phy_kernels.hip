@@ -368,8 +368,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                 wave_sync();
             } else {
                 // ---------------- the heuristics of phy_rmsa_env.py:1254-1737
-                const bool with_metric = policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC;
-                const bool groom = with_metric ? (p.grooming != 0) : true;
+                const bool faff = policy == ORLG_PHY_POLICY_FAFF || policy == ORLG_PHY_POLICY_FAFF_RSS;
+                const bool bmfa = policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC;
+                const bool with_metric = bmfa || faff;
+                const bool groom = bmfa ? (p.grooming != 0) : true;
                 bool served = false;
                 if (groom) {
                     // use_existing_channels (:1650-1673): residual capacity on channels this (src, dst, k-path) already lights
@@ -403,8 +405,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                     //   bmff:            sorted(row, key=(-level, channel)),  row with the best head level (ties: lower index)
                     //   sapbm:           sorted(row, key=(-level, channel)),  first non-empty row
                     //   sapff:           sorted(row, key=channel),            first non-empty row
-                    const int metric_mode = policy == ORLG_PHY_POLICY_BMFA_CUT ? 0 : policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC ? 1 : 2;
-                    const bool flat = policy == ORLG_PHY_POLICY_SAPFF;
+                    //   faff / faff_rss: sorted(row, key=-metric),            row with the best head metric (ties: lower index)
+                    const int metric_mode = (policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_FAFF) ? 0
+                                            : (policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC || policy == ORLG_PHY_POLICY_FAFF_RSS) ? 1 : 2;
+                    const bool flat = policy == ORLG_PHY_POLICY_SAPFF || faff;  // the level is not a sort key
                     const bool first_row = policy == ORLG_PHY_POLICY_SAPFF || policy == ORLG_PHY_POLICY_SAPBM;
                     const int pp = lane / W, pw = lane - pp * W;
                     const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);

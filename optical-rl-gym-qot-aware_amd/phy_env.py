@@ -336,12 +336,46 @@ def _pick_level_metric(rows):
     return best
 
 
+def _cut_metric(e, ch, links, path):
+    return e.calculate_r_cut(ch, links, False, path, True)
+
+
+def _rss_metric(e, ch, links, path):
+    return e.calculate_r_spatial(ch, links, False)
+
+
+def _faff(env, metric):
+    v = _with_virtual_layer(env, True)
+    if v:
+        return v
+    rows = [sorted(r, key=lambda x: -x[1]) for r in _free_channel_rows(env, metric)]
+
+    def pick(rows):
+        best, head = None, float("-inf")
+        for i, row in enumerate(rows):
+            if row[0][1] > head:
+                best, head = i, row[0][1]
+        return best
+    return _take_channels(env, rows, pick)
+
+
+def phy_aware_faff_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1508-1569``: virtual layer first, then fragmentation-aware first: channels by cut metric
+    (desc, ties in index order) whatever their modulation level, the path whose best channel has the highest metric."""
+    return _faff(env, _cut_metric)
+
+
+def phy_aware_faff_rss_rmsa(env) -> Tuple[int, list]:
+    """``phy_rmsa_env.py:1572-1647``: as faff with the RSS metric."""
+    return _faff(env, _rss_metric)
+
+
 def phy_aware_bmfa_rss_rmsa(env) -> Tuple[int, list]:
     """``phy_rmsa_env.py:1441-1505``: as bmfa with the RSS metric (``calculate_r_spatial``)."""
     v = _with_virtual_layer(env, False)
     if v:
         return v
-    rows = _free_channel_rows(env, lambda e, ch, links, path: e.calculate_r_spatial(ch, links, False))
+    rows = _free_channel_rows(env, _rss_metric)
     return _take_channels(env, [sorted(r, key=lambda x: (-x[0], -x[1])) for r in rows], _pick_level_metric)
 
 

@@ -276,7 +276,7 @@ def py_random_stream(seed, n):
 
 # ----------------------------------------------------------------------------------------- PhyRMSA oracle
 PHY_MAX_CH = 12
-PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4}
+PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff": 5, "faff_rss": 6}
 
 
 class PhyConfig(C.Structure):

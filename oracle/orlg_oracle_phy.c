@@ -6,8 +6,8 @@
  * link axis for the cut / RSS fragmentation metrics, a binary heap of release events, ordered
  * residual-capacity lists channel_state[src, dst, k-path] for the virtual "grooming" layer).  Heuristics:
  * phy_aware_bmfa_rmsa / phy_aware_bmfa_rss_rmsa (which honour env.grooming) and sapff_rmsa /
- * phy_aware_bmff_rmsa / phy_aware_sapbm_rmsa (which ALWAYS try use_existing_channels first, whatever
- * env.grooming says: phy_rmsa_env.py:1256,1321,1678).  NOT restated: the periodic defragmentation
+ * phy_aware_bmff_rmsa / phy_aware_sapbm_rmsa / phy_aware_faff_rmsa / phy_aware_faff_rss_rmsa (which ALWAYS try
+ * use_existing_channels first, whatever env.grooming says: phy_rmsa_env.py:1256,1321,1510,1574,1678).  NOT restated: the periodic defragmentation
  * (defrag_period, phy_rmsa_env.py:355-417, 662-764).
  *
  * Pinned bit for bit (floats included) against tests/golden/phy_*.npz recorded from the reference.
@@ -328,6 +328,11 @@ static int cmp_level_frag(const void *a, const void *b) { /* key (-x[0], -x[1]);
     if (x->frag != y->frag) return x->frag > y->frag ? -1 : 1;
     return x->pos - y->pos;
 }
+static int cmp_frag(const void *a, const void *b) { /* key (-x[1]); stable (phy_rmsa_env.py:1538, 1601) */
+    const cand *x = (const cand *)a, *y = (const cand *)b;
+    if (x->frag != y->frag) return x->frag > y->frag ? -1 : 1;
+    return x->pos - y->pos;
+}
 static int cmp_level_ch(const void *a, const void *b) { /* key (-x[0], x[1]) */
     const cand *x = (const cand *)a, *y = (const cand *)b;
     if (x->key0 != y->key0) return x->key0 < y->key0 ? -1 : 1;
@@ -376,7 +381,9 @@ void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
     cand *rows = (cand *)malloc(sizeof(cand) * (size_t)K * C);
     int *cnt = (int *)calloc(K, sizeof(int));
     int *alive = (int *)malloc(sizeof(int) * K);
-    const int with_metric = policy == ORC_PHY_POLICY_BMFA || policy == ORC_PHY_POLICY_BMFA_RSS;
+    const int faff = policy == ORC_PHY_POLICY_FAFF || policy == ORC_PHY_POLICY_FAFF_RSS;
+    const int rss = policy == ORC_PHY_POLICY_BMFA_RSS || policy == ORC_PHY_POLICY_FAFF_RSS;
+    const int with_metric = policy == ORC_PHY_POLICY_BMFA || policy == ORC_PHY_POLICY_BMFA_RSS || faff;
     for (int idp = 0; idp < K; idp++) {
         int gid = ppath_gid(e, s->src, s->dst, idp);
         alive[idp] = 1;
@@ -384,11 +391,12 @@ void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
             if (is_channel_free(e, gid, ch)) {
                 cand *c = &rows[(size_t)idp * C + cnt[idp]];
                 c->mod = e->cfg.modulation_level[((size_t)row * C + ch) * e->cfg.k_table + idp];
-                c->frag = !with_metric ? 0.0 : policy == ORC_PHY_POLICY_BMFA_RSS ? r_spatial(e, gid, ch) : (double)r_cut_modified(e, gid, ch);
+                c->frag = !with_metric ? 0.0 : rss ? r_spatial(e, gid, ch) : (double)r_cut_modified(e, gid, ch);
                 c->ch = ch; c->idp = idp; c->pos = cnt[idp]; c->key0 = (uint8_t)(-c->mod);
                 cnt[idp]++;
             }
-        if (with_metric) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_level_frag);
+        if (faff) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_frag);
+        else if (with_metric) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_level_frag);
         else if (policy != ORC_PHY_POLICY_SAPFF) qsort(&rows[(size_t)idp * C], cnt[idp], sizeof(cand), cmp_level_ch);
         /* sapff: key x[1] = channel, already ascending */
     }
@@ -398,6 +406,13 @@ void orc_phy_policy(orc_phy_env *e, int policy, orc_phy_action *act) {
             /* empty rows are dropped, the first remaining row is used (phy_rmsa_env.py:1289-1297, 1711-1719) */
             for (int i = 0; i < K && best < 0; i++)
                 if (alive[i] && cnt[i] > 0) best = i;
+        } else if (faff) {
+            /* the row whose head has the best metric, ties keep the lower row (phy_rmsa_env.py:1546-1551) */
+            double max_frag = -INFINITY;
+            for (int i = 0; i < K; i++) {
+                if (!alive[i] || cnt[i] == 0) continue;
+                if (rows[(size_t)i * C].frag > max_frag) { max_frag = rows[(size_t)i * C].frag; best = i; }
+            }
         } else {
             double max_mod = -INFINITY, max_frag = -INFINITY;
             for (int i = 0; i < K; i++) {

@@ -31,7 +31,7 @@ typedef struct orc_phy_config {
 } orc_phy_config;
 
 enum { ORC_PHY_POLICY_BMFA = 0, ORC_PHY_POLICY_BMFA_RSS = 1, ORC_PHY_POLICY_SAPFF = 2, ORC_PHY_POLICY_BMFF = 3,
-       ORC_PHY_POLICY_SAPBM = 4 };
+       ORC_PHY_POLICY_SAPBM = 4, ORC_PHY_POLICY_FAFF = 5, ORC_PHY_POLICY_FAFF_RSS = 6 };
 
 typedef struct orc_phy_action {
     int32_t path;   /* -2 = blocked; 20 + idp = served on the virtual layer (phy_rmsa_env.py:280-288) */

@@ -425,7 +425,8 @@ def run_phy_trace(topo, tables, env_kwargs, policy, n_steps, reset_on_done):
     conn, mod, gsnr = tables
     env = P.PhyRMSAEnv(topology=topo, modulation_level=mod, connections_detail=conn, gsnr=gsnr, **env_kwargs)
     pol = {"bmfa": P.phy_aware_bmfa_rmsa, "bmfa_rss": P.phy_aware_bmfa_rss_rmsa, "sapff": P.sapff_rmsa,
-           "bmff": P.phy_aware_bmff_rmsa, "sapbm": P.phy_aware_sapbm_rmsa}[policy]
+           "bmff": P.phy_aware_bmff_rmsa, "sapbm": P.phy_aware_sapbm_rmsa, "faff": P.phy_aware_faff_rmsa,
+           "faff_rss": P.phy_aware_faff_rss_rmsa}[policy]
     rec = Recorder()
     MAXCH = 12
     chans, used, free, cap = [], [], [], []
@@ -488,6 +489,9 @@ PHY_CASES = [
     ("phy_us14_s13_bmfa_rss_groom_load3000", "us14_k3", dict(seed=13, load=3000, grooming=True), "bmfa_rss", 1200, True),
     ("phy_us14_s14_sapff_load4000", "us14_k3", dict(seed=14, load=4000), "sapff", 2600, True),  # reaches blocking
     ("phy_jpn12_s5_bmff", "jpn12_k3", dict(seed=5, load=900), "bmff", 800, True),
+    # fragmentation-aware first fit (tests/test_rmsa_threads_us.py:87-108)
+    ("phy_us14_s10_faff", "us14_k3", dict(), "faff", 600, True),
+    ("phy_us14_s15_faff_rss_load2400", "us14_k3", dict(seed=15, load=2400), "faff_rss", 800, True),
 ]
 
 

@@ -24,7 +24,8 @@ def make_env(topo, tables, kw, batch, **extra):
                                        ("phy_us14_s10_sapff", 800), ("phy_us14_s10_bmff", 800),
                                        ("phy_us14_s10_sapbm", 800), ("phy_us14_s11_bmfa_load2400", 1500),
                                        ("phy_us14_s10_bmfa_groom", 800), ("phy_us14_s13_bmfa_rss_groom_load3000", 1200),
-                                       ("phy_us14_s14_sapff_load4000", 2600), ("phy_jpn12_s5_bmff", 800)])
+                                       ("phy_us14_s14_sapff_load4000", 2600), ("phy_jpn12_s5_bmff", 800),
+                                       ("phy_us14_s10_faff", 600), ("phy_us14_s15_faff_rss_load2400", 800)])
 def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     z, meta = load_golden(case)
     topo = load_topology(meta["topology"])

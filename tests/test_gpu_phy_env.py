@@ -36,7 +36,8 @@ def test_phy_view_bmfa_matches_reference():
 @pytest.mark.parametrize("case,heuristic,n", [("phy_us14_s10_sapff", "sapff_rmsa", 260), ("phy_us14_s10_bmff", "phy_aware_bmff_rmsa", 120),
                                               ("phy_us14_s10_sapbm", "phy_aware_sapbm_rmsa", 120),
                                               ("phy_us14_s10_bmfa_groom", "phy_aware_bmfa_rmsa", 120),
-                                              ("phy_us14_s10_bmfa_rss", "phy_aware_bmfa_rss_rmsa", 60)])
+                                              ("phy_us14_s10_bmfa_rss", "phy_aware_bmfa_rss_rmsa", 60),
+                                              ("phy_us14_s10_faff", "phy_aware_faff_rmsa", 80)])
 def test_phy_view_heuristics_with_virtual_layer(case, heuristic, n):
     """The heuristic callbacks on the single-env view (incl. use_existing_channels on env.channel_state and virtual-layer
     actions path = 20 + k-path) reproduce the reference's trace."""
