@@ -187,7 +187,7 @@ int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */)
 
 /* ------------------------------------------------------------------------------------------------
  * QoT-aware environment: PhyRMSAEnv (optical_rl_gym/envs/phy_rmsa_env.py), physical layer + virtual ("grooming")
- * layer, without the periodic defragmentation (defrag_period).  Allocation is per CHANNEL (L+C+S bands = 268
+ * layer + periodic defragmentation.  Allocation is per CHANNEL (L+C+S bands = 268
  * channels, non-contiguous); the QoT gate is the table modulation_level[pair row][channel][k-path] (capacity = level
  * x 100 Gb/s); GSNR[...] feeds the statistics.  A service that does not use the whole capacity of its last channel
  * leaves the rest in channel_state[src, dst, k-path] (phy_rmsa_env.py:600-602), where use_existing_channels (:1650-1673)
@@ -203,6 +203,10 @@ typedef struct orlg_phy_config {
     int32_t grooming;         /* env.grooming (phy_rmsa_env.py:57): bmfa / bmfa_rss consult the virtual layer only when set;
                                * sapff / bmff / sapbm always do (:1256, 1321, 1678) */
     int32_t channel_state_capacity; /* entries per channel_state[src, dst, k-path] list (8..64); 0 = from the load */
+    /* periodic defragmentation (phy_rmsa_env.py:54-56, 355-417): every defrag_period processed services, at most
+     * number_moves (+1) reallocations ranked by the cut (0) or RSS (1) metric; defrag_period 0 = off */
+    int32_t defrag_period, number_moves, defrag_metric;
+    int32_t defrag_capacity;  /* entries of the per-env defragmentation work list; 0 = 2 x queue capacity */
     double arrival_lambda, holding_lambda;
     const int32_t *bit_rates;           /* [num_bit_rates], default 100..600 (phy_rmsa_env.py:38) */
     const double *bit_rate_cum, *src_cum, *dst_cum;
@@ -236,12 +240,15 @@ typedef struct orlg_phy_step_io { /* optional per-step outputs, [n_steps][B] eac
     double *number_cuts_total;  /* info["number_cuts_total"] (_calculate_total_cuts, phy_rmsa_env.py:1195-1203) */
     double *rss_total_metric;   /* info["rss_total_metric"] (calculate_total_r_spatial, :1110-1121) */
     int16_t *channels_used;     /* [n_steps][B][ORLG_PHY_MAX_CHANNELS] share of each channel the service uses, 100 Gb/s units */
+    int32_t *defrag_counters;   /* [n_steps][B][3] counted_moves, counted_moves_groom, counted_defrag_cycles as the step's info
+                                 * dict sees them (phy_rmsa_env.py:340-342: before the step's own defragmentation) */
 } orlg_phy_step_io;
 
 typedef struct orlg_phy_episode_stats { /* per-episode sums behind the info dict (phy_rmsa_env.py:339-347) */
     double total_path_length, total_gsnr;
     int64_t total_path_index, total_modulation_level, channels_accepted, physical_services_accepted;
     int64_t episodes_done, queue_overflow;
+    int64_t counted_moves, counted_moves_groom, counted_defrag_cycles; /* phy_rmsa_env.py:110-112 */
 } orlg_phy_episode_stats;
 
 typedef struct orlg_phy_env orlg_phy_env;

@@ -53,6 +53,8 @@ class PhyConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
                 ("k_table", C.c_int32), ("num_table_rows", C.c_int32), ("queue_capacity", C.c_int32),
                 ("grooming", C.c_int32), ("channel_state_capacity", C.c_int32),
+                ("defrag_period", C.c_int32), ("number_moves", C.c_int32), ("defrag_metric", C.c_int32),
+                ("defrag_capacity", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight")]
@@ -61,13 +63,14 @@ class PhyConfig(C.Structure):
 class PhyStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_path", "n_channels", "channels", "accepted", "done", "request",
                                          "arrival", "holding", "number_cuts_total", "rss_total_metric",
-                                         "channels_used")]
+                                         "channels_used", "defrag_counters")]
 
 
 PHY_MAX_CHANNELS = 14
 PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
                       "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
-                      "number_cuts_total": "float64", "rss_total_metric": "float64", "channels_used": "int16"}
+                      "number_cuts_total": "float64", "rss_total_metric": "float64", "channels_used": "int16",
+                      "defrag_counters": "int32"}
 PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff": 5, "faff_rss": 6}
 
 _lib = None

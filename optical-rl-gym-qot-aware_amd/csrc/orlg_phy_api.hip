@@ -70,6 +70,8 @@ __global__ void orlg_phy_extract_kernel(OrlgPhyParams p, int what, unsigned char
             o[i].total_path_index = s.total_path_index; o[i].total_modulation_level = s.total_mod;
             o[i].channels_accepted = s.channels_accepted; o[i].physical_services_accepted = s.physical_accepted;
             o[i].episodes_done = s.episodes_done; o[i].queue_overflow = s.q_overflow;
+            o[i].counted_moves = s.counted_moves; o[i].counted_moves_groom = s.counted_moves_groom;
+            o[i].counted_defrag_cycles = s.counted_defrag_cycles;
         }
     }
 }
@@ -184,6 +186,9 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     p.episode_length = c->episode_length; p.num_rows = c->num_table_rows; p.cpad = W * 64;
     p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
     p.grooming = c->grooming ? 1 : 0;
+    p.defrag_period = c->defrag_period > 0 ? c->defrag_period : 0;
+    p.number_moves = c->number_moves; p.defrag_metric = c->defrag_metric ? 1 : 0;
+    if (p.defrag_period > 0 && p.number_moves < 0) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "number_moves must be >= 0"); }
     {
         // channel_state[src, dst, k-path] lists (virtual layer): one entry per lit, partially used channel of the
         // (pair, path); sized from the mean number of services per ordered pair, overflow is reported, never dropped
@@ -332,6 +337,12 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     TRY(alloc(reinterpret_cast<void **>(&p.scal), (size_t)batch * sizeof(OrlgPhyScalars)));
     TRY(alloc(reinterpret_cast<void **>(&p.cs), (size_t)batch * N * N * K * p.cs_len * 4));
     TRY(alloc(reinterpret_cast<void **>(&p.cs_n), (size_t)batch * N * N * K));
+    if (p.defrag_period > 0) {
+        // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
+        p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;
+        if (Q > 65535) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "defragmentation needs queue_capacity < 65536"); }
+        TRY(alloc(reinterpret_cast<void **>(&p.cand), (size_t)batch * p.cand_cap * sizeof(OrlgPhyCand)));
+    }
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
         for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
@@ -409,7 +420,8 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
         {io ? io->act_path : nullptr, 4},  {io ? io->n_channels : nullptr, 4}, {io ? io->channels : nullptr, 2 * ORLG_PHY_MAX_CH},
         {io ? io->accepted : nullptr, 1},  {io ? io->done : nullptr, 1},       {io ? io->request : nullptr, 16},
         {io ? io->arrival : nullptr, 8},   {io ? io->holding : nullptr, 8},    {io ? io->number_cuts_total : nullptr, 8},
-        {io ? io->rss_total_metric : nullptr, 8}, {io ? io->channels_used : nullptr, 2 * ORLG_PHY_MAX_CH}};
+        {io ? io->rss_total_metric : nullptr, 8}, {io ? io->channels_used : nullptr, 2 * ORLG_PHY_MAX_CH},
+        {io ? io->defrag_counters : nullptr, 12}};
     bool staged[ORLG_PHY_NUM_OUTS] = {false};
     p.out_mask = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) {
@@ -508,7 +520,7 @@ int orlg_phy_reduce_counters(orlg_phy_env *e, int64_t *out) {
     HIP_TRY(hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(out, d, 16 * 8, hipMemcpyDefault, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (host[10]) return fail(ORLG_ERR_QUEUE_FULL, "a release queue overflowed (capacity %d): raise queue_capacity", e->p.Q);
+    if (host[10]) return fail(ORLG_ERR_QUEUE_FULL, "a release queue (capacity %d), channel_state list (capacity %d) or defragmentation work list (capacity %d) overflowed: raise queue_capacity / channel_state_capacity / defrag_capacity", e->p.Q, e->p.cs_len, e->p.cand_cap);
     return ORLG_OK;
 }
 

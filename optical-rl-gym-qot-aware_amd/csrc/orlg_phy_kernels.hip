@@ -5,7 +5,8 @@
 // calculate_r_cut (modified) :1123-1193, calculate_r_spatial :1085-1108, _calculate_total_cuts :1195-1203,
 // calculate_total_r_spatial :1110-1121, heuristics phy_aware_sapbm_rmsa :1254, phy_aware_bmff_rmsa :1317,
 // phy_aware_bmfa_rmsa :1375, phy_aware_bmfa_rss_rmsa :1441, use_existing_channels :1650, sapff_rmsa :1676.
-// Not built: the periodic defragmentation (defrag_period, :355-417, 662-764).
+// Periodic defragmentation (defrag_period, number_moves, metric): step :355-417, _move :662-697,
+// _groom_defragmentation :703-733, _move_virtual :735-764 -- phy_defragmentation below.
 //
 // Same execution model as orlg_kernels.hip: one wavefront per environment, the link x channel free bitmap
 // (268 channels = 5 words per link), the release-time array and the MT19937 state live in LDS for the whole
@@ -20,10 +21,16 @@
 #define ORLG_PHY_MAX_K 5
 
 struct __attribute__((aligned(16))) OrlgPhySvc {  // one running service (HBM)
+    double arrival;                // service.arrival_time (age of a defragmentation candidate)
+    uint32_t seq;                  // ascending seq = order of topology.graph["running_services"] (remove + append = new seq)
     uint16_t gid;
     uint8_t nch, flags;            // flags bit 0: served on the virtual layer; bit 1: source index > destination index
-    uint16_t ch[ORLG_PHY_MAX_CH];  // channel | used << 9 | partial << 14  (partial: used != capacity)
+    uint16_t ch[ORLG_PHY_MAX_CH];  // service.channels in list order: channel | used << 9 | partial << 14  (partial: used != capacity)
 };
+// one entry of the per-env defragmentation work list (HBM): a candidate (diff, age, seq, idx, channel | position << 9)
+// of the physical pass or a groom-eligible service (seq, idx) of the grooming pass
+struct OrlgPhyCand { double diff, age; uint32_t seq; uint16_t idx, chj; };
+static_assert(sizeof(OrlgPhyCand) == 24, "OrlgPhyCand layout");
 #define ORLG_CS_MAX 64             // entries per channel_state[src, dst, k-path] list: p.cs_len <= one wavefront
 // one channel_state tuple (channel, used, free, capacity), 100 Gb/s units: ch | used << 9 | free << 14 | cap << 19 | 1 << 31
 DEV uint32_t cs_pack(int ch, int used, int free_, int cap) {
@@ -33,7 +40,7 @@ DEV int cs_ch(uint32_t e) { return (int)(e & 0x1ffu); }
 DEV int cs_used(uint32_t e) { return (int)((e >> 9) & 0x1fu); }
 DEV int cs_free(uint32_t e) { return (int)((e >> 14) & 0x1fu); }
 DEV int cs_cap(uint32_t e) { return (int)((e >> 19) & 0x1fu); }
-static_assert(sizeof(OrlgPhySvc) == 32, "OrlgPhySvc layout");
+static_assert(sizeof(OrlgPhySvc) == 48, "OrlgPhySvc layout");
 
 // per-env scalars in HBM (256 B)
 struct __attribute__((aligned(16))) OrlgPhyScalars {
@@ -43,19 +50,21 @@ struct __attribute__((aligned(16))) OrlgPhyScalars {
     int64_t total_path_index, total_mod, channels_accepted, physical_accepted;
     int64_t episodes_done;
     int32_t n_running, req_src, req_dst, req_br, req_sid, mt_idx, new_service, q_overflow;
-    int32_t pad[10];
+    int32_t next_seq, counted_moves, counted_moves_groom, counted_defrag_cycles;  // phy_rmsa_env.py:110-112
+    int32_t pad[6];
 };
 static_assert(sizeof(OrlgPhyScalars) == 224, "OrlgPhyScalars layout");
 
 // policies: ORLG_PHY_POLICY_* of include/orlg.h
 enum { ORLG_PHY_OUT_PATH = 0, ORLG_PHY_OUT_NCH, ORLG_PHY_OUT_CHANNELS, ORLG_PHY_OUT_ACCEPTED, ORLG_PHY_OUT_DONE,
        ORLG_PHY_OUT_REQUEST, ORLG_PHY_OUT_ARRIVAL, ORLG_PHY_OUT_HOLDING, ORLG_PHY_OUT_CUTS, ORLG_PHY_OUT_RSS,
-       ORLG_PHY_OUT_CH_USED, ORLG_PHY_NUM_OUTS };
+       ORLG_PHY_OUT_CH_USED, ORLG_PHY_OUT_DEFRAG, ORLG_PHY_NUM_OUTS };
 
 struct OrlgPhyParams {
     int32_t B, N, E, C, K, NBR, Q, NW;
     int32_t episode_length, n_steps, policy, auto_reset, mode, out_mask, num_rows, cpad;
     int32_t grooming, cs_len;
+    int32_t defrag_period, number_moves, defrag_metric /* 0 cut, 1 rss */, cand_cap;
     double arrival_lambda, holding_lambda;
     // per-env state in HBM
     uint64_t *occ;          // [B][E*W]
@@ -65,6 +74,7 @@ struct OrlgPhyParams {
     OrlgPhyScalars *scal;   // [B]
     uint32_t *cs;           // [B][N*N*K][cs_len] channel_state lists (virtual layer), list order = array order
     uint8_t *cs_n;          // [B][N*N*K] list lengths
+    OrlgPhyCand *cand;      // [B][cand_cap] defragmentation work list (only with defrag_period > 0)
     // shared tables
     const unsigned char *tables;   // blob staged into LDS
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
@@ -83,7 +93,7 @@ struct PhyWaveScalars {  // LDS
     int64_t c[8];
     int64_t total_path_index, total_mod, channels_accepted, physical_accepted, episodes_done;
     double total_path_length, total_gsnr, req_arrival, req_holding;
-    int32_t q_overflow, pad;
+    int32_t q_overflow, counted_moves, counted_moves_groom, counted_defrag_cycles;
 };
 
 struct PhyTab {
@@ -168,10 +178,9 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
 //   rss (calculate_r_spatial, :1085-1108): sqrt(sum len^2) / (sum len + 1) over the free runs of the channel's column
 //   along the link axis, after taking the channel on the path's links minus before.
 template <int W>
-DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, int row, int lane,
-                         int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W]) {
+DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, const uint8_t *mrow,
+                         int lane, int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W]) {
     const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
-    const uint8_t *mrow = p.mod_t + (size_t)(row * p.K + idp) * p.cpad;
     // links of the path as a bit set (E <= 255: four words)
     const OrlgPathRec *rec = tb.recs + gid;
 #pragma unroll
@@ -280,6 +289,305 @@ DEV bool cs_append(CsList &l, uint32_t v, int lane) {  // list.append
     return true;
 }
 
+
+// channel_state list of a running service: (source, destination, k-path) key from its path record and direction flag
+DEV int svc_key(const PhyTab &tb, int N, int K, int gid, int flags) {
+    const int pair = tb.path_pair[gid];
+    const int pa = pair / N, pb = pair - pa * N;
+    const int s = (flags & 2) ? pb : pa, d = (flags & 2) ? pa : pb;
+    return (s * N + d) * K + (gid - tb.pair_base[pair]);
+}
+
+// calculate_r_cut(modified=True) on ONE lane for channel `ch` of path `gid`: sum_j weight_j * (1 - 2 * available[link_j][ch])
+// = cuts before minus after taking a free channel; the negative is the gain of releasing an occupied one (defrag_flag=True)
+DEV int lane_cut_sum(const u64 *occ, const PhyTab &tb, int gid, int ch, int W) {
+    int m = 0;
+    const int w = ch >> 6, b = ch & 63;
+    for (int j = tb.adj_off[gid]; j < tb.adj_off[gid + 1]; ++j) {
+        const unsigned aw = tb.adj[j];
+        const int bit = (int)((occ[__mul24((int)(aw & 0xffu), W) + w] >> b) & 1ull);
+        m += (int)(aw >> 8) * (1 - 2 * bit);
+    }
+    return m;
+}
+
+// calculate_r_spatial on ONE lane (phy_rmsa_env.py:1085-1108): RSS of channel ch's column with the path's links forced
+// to `force` (0: taken, 1: released = defrag_flag) minus the RSS of the column as it is
+DEV double lane_rss_delta(const u64 *occ, const double *sqrt_tab, const OrlgPathRec *rec, int ch, int E, int W, int force) {
+    u64 pm[4] = {0ull, 0ull, 0ull, 0ull};
+    const int hops = rec->hops;
+    for (int h = 0; h < hops; ++h) {
+        const int pl = (int)rec->link[h];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if ((pl >> 6) == q) pm[q] |= 1ull << (pl & 63);
+    }
+    const int w = ch >> 6, bpos = ch & 63;
+    int cur0 = 0, sq0 = 0, sm0 = 0, cur1 = 0, sq1 = 0, sm1 = 0;
+    for (int l = 0; l < E; ++l) {
+        const int b = (int)((occ[__mul24(l, W) + w] >> bpos) & 1ull);
+        const u64 pw = (l >> 6) == 0 ? pm[0] : (l >> 6) == 1 ? pm[1] : (l >> 6) == 2 ? pm[2] : pm[3];
+        const int b1 = ((pw >> (l & 63)) & 1ull) ? force : b;
+        if (b) { cur0 += 1; } else { sq0 += cur0 * cur0; sm0 += cur0; cur0 = 0; }
+        if (b1) { cur1 += 1; } else { sq1 += cur1 * cur1; sm1 += cur1; cur1 = 0; }
+    }
+    sq0 += cur0 * cur0; sm0 += cur0; sq1 += cur1 * cur1; sm1 += cur1;
+    return ORLG_FDIV(sqrt_tab[sq1], (double)(sm1 + 1)) - ORLG_FDIV(sqrt_tab[sq0], (double)(sm0 + 1));
+}
+
+DEV u64 wave_min_u64(u64 v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// The periodic defragmentation of PhyRMSAEnv.step (phy_rmsa_env.py:355-417), run when services_processed is a multiple of
+// defrag_period, right after _next_service.  Two passes:
+//  1. _groom_defragmentation (:703-733): a service that is the ONLY user of a partially used channel moves that share
+//     onto another lit channel of its (source, destination, k-path) with enough residual capacity (_move_virtual); the
+//     old channel goes dark.  The reference walks running_services / service.channels while it mutates them (remove +
+//     append): the element after a moved one is skipped and the moved one is met again at the end.  Eligibility can only
+//     be lost during the pass (residual capacities shrink, users are only added), so the services eligible at the start
+//     -- found by all lanes in parallel -- plus the ones re-appended by a move are the only ones the walk can act on;
+//     they are visited in list order (ascending seq) and re-checked exactly at their turn.
+//  2. physical pass (:359-417): every channel a service fills, whose release would improve the metric, is a candidate
+//     (metric gain, age); in (gain, age) order each candidate looks for a free channel of the same modulation level on
+//     its path and moves there (_move, :662-697) when placing costs less than releasing gains.
+template <int W>
+DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
+                             uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, int n_running, int &next_seq,
+                             double current_time, int req_src, int req_dst, int lane) {
+    const int N = p.N, K = p.K, E = p.E;
+    const bool rss = p.defrag_metric != 0;
+    bool overflow = false;
+    // ------------------------------------------------------------------ 1. grooming pass
+    int n_el = 0;
+    for (int i0 = 0; i0 < n_running; i0 += 64) {
+        const int idx = i0 + lane;
+        bool elig = false;
+        uint32_t seq = 0;
+        if (idx < n_running) {
+            const OrlgPhySvc *r = grec + idx;
+            const int gid = r->gid, nch = r->nch;
+            seq = r->seq;
+            const int key = svc_key(tb, N, K, gid, r->flags);
+            const int n = gcs_n[key];
+            const uint32_t *lst = gcs + (size_t)key * p.cs_len;
+            for (int j = 0; j < nch && !elig; ++j) {
+                const int raw = r->ch[j];
+                if (raw & (1 << 14)) {
+                    const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
+                    bool sole = false, target = false;
+                    for (int t = 0; t < n; ++t) {
+                        const uint32_t en = lst[t];
+                        if (cs_ch(en) == ch) sole = sole || cs_used(en) == mine;
+                        else target = target || cs_free(en) >= mine;
+                    }
+                    elig = sole && target;
+                }
+            }
+        }
+        const u64 m = ballot(elig);
+        if (m) {
+            const int pos = n_el + popc64(m & ((1ull << lane) - 1ull));
+            if (elig && pos < p.cand_cap) { cand[pos].seq = seq; cand[pos].idx = (uint16_t)idx; }
+            n_el += popc64(m);
+        }
+    }
+    if (n_el > p.cand_cap) { overflow = true; n_el = p.cand_cap; }
+    int gmoves = 0;
+    {
+        long long cursor = -1;
+        bool stop = p.number_moves == 0;  // the reference returns at its first check
+        for (int visit = 0; visit < 2 * p.cand_cap && !stop; ++visit) {  // every visit moves the cursor up the list
+            u64 bk = ~0ull;
+            for (int c = lane; c < n_el; c += 64) {
+                const uint32_t sq = cand[c].seq;
+                if ((long long)sq > cursor) { const u64 k = ((u64)sq << 32) | cand[c].idx; bk = k < bk ? k : bk; }
+            }
+            bk = wave_min_u64(bk);
+            if (bk == ~0ull) break;
+            const int idx = (int)(uint32_t)bk;
+            const uint32_t seq0 = (uint32_t)(bk >> 32);
+            const OrlgPhySvc *r = grec + idx;
+            const int gid = uni((int)r->gid), nch = uni((int)r->nch), flags = uni((int)r->flags);
+            if (lane < ORLG_PHY_MAX_CH) lch[lane] = lane < nch ? (int)r->ch[lane] : 0xffff;
+            wave_sync();
+            const int key = svc_key(tb, N, K, gid, flags);
+            const OrlgPathRec *rec = tb.recs + gid;
+            bool moved = false;
+            for (int j = 0; j < nch; ++j) {  // the list keeps its length: every move is remove + append
+                const int raw = lch[j];
+                if (raw & (1 << 14)) {
+                    const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
+                    CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+                    const int q = cs_find(l, ch, lane);
+                    if (q >= 0 && cs_used(cs_get(l, q)) == mine) {
+                        const u64 tm = ballot(lane < l.n && cs_ch(l.e) != ch && cs_free(l.e) >= mine);
+                        if (tm) {
+                            const uint32_t tg = cs_get(l, ctz64(tm));
+                            cs_remove(l, ctz64(tm), lane);
+                            cs_remove(l, cs_find(l, ch, lane), lane);
+                            cs_append(l, cs_pack(cs_ch(tg), cs_used(tg) + mine, cs_free(tg) - mine, cs_cap(tg)), lane);
+                            cs_store(gcs, gcs_n, key, l, lane);
+                            // _move_virtual (:735-764): the old channel goes dark on the path, the list entry moves to the end
+                            if (lane < rec->hops) occ[(int)rec->link[lane] * W + (ch >> 6)] |= 1ull << (ch & 63);
+                            wave_sync();
+                            const int nxt = (lane >= j && lane + 1 < nch) ? lch[lane + 1] : 0;
+                            wave_sync();
+                            if (lane >= j && lane + 1 < nch) lch[lane] = nxt;
+                            if (lane == nch - 1) lch[lane] = cs_ch(tg) | (mine << 9) | (1 << 14);
+                            wave_sync();
+                            moved = true;
+                            gmoves += 1;
+                        }
+                    }
+                }
+                if (gmoves == p.number_moves) { stop = true; break; }
+            }
+            if (moved) {
+                const int ns = next_seq;
+                next_seq += 1;
+                if (lane < nch) grec[idx].ch[lane] = (uint16_t)lch[lane];
+                if (lane == 0) grec[idx].seq = (uint32_t)ns;
+                // the list iterator skips the service that followed this one (it slid into its place)
+                u64 smin = ~0ull;
+                for (int i = lane; i < n_running; i += 64) {
+                    const uint32_t sq = grec[i].seq;
+                    if (sq > seq0) smin = (u64)sq < smin ? (u64)sq : smin;
+                }
+                smin = wave_min_u64(smin);
+                cursor = (long long)smin;
+                if (n_el < p.cand_cap) {
+                    if (lane == 0) { cand[n_el].seq = (uint32_t)ns; cand[n_el].idx = (uint16_t)idx; }
+                    n_el += 1;
+                } else {
+                    overflow = true;
+                }
+            } else {
+                cursor = (long long)seq0;
+            }
+            wave_sync();
+        }
+    }
+    int cmoves = 0, cycles = 0;
+    // ------------------------------------------------------------------ 2. physical pass
+    if (gmoves <= p.number_moves) {
+        int nc = 0;
+        for (int i0 = 0; i0 < n_running; i0 += 64) {
+            const int idx = i0 + lane;
+            const bool act = idx < n_running;
+            const OrlgPhySvc *r = grec + (act ? idx : 0);
+            const int my_n = act ? (int)r->nch : 0, my_gid = (int)r->gid;
+            const uint32_t my_seq = r->seq;
+            const double my_arrival = r->arrival;
+            int maxn = my_n;
+            for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
+            maxn = uni(maxn);
+            for (int j = 0; j < maxn; ++j) {
+                bool is_c = false;
+                double diff = 0.0;
+                int ch = 0;
+                if (j < my_n) {
+                    const int raw = (int)r->ch[j];
+                    if (!(raw & (1 << 14))) {  // only channels the service fills are reallocated
+                        ch = raw & 0x1ff;
+                        diff = rss ? lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1) : (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
+                        is_c = diff > 0.0;
+                    }
+                }
+                const u64 m = ballot(is_c);
+                if (m) {
+                    const int pos = nc + popc64(m & ((1ull << lane) - 1ull));
+                    if (is_c && pos < p.cand_cap) {
+                        OrlgPhyCand c;
+                        c.diff = diff; c.age = current_time - my_arrival; c.seq = my_seq; c.idx = (uint16_t)idx; c.chj = (uint16_t)(ch | (j << 9));
+                        cand[pos] = c;
+                    }
+                    nc += popc64(m);
+                }
+            }
+        }
+        if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
+        wave_sync();
+        for (int round = 0; round < nc; ++round) {  // every round retires one candidate
+            // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
+            double bd = -1.0, ba = 0.0;
+            u64 bo = ~0ull;
+            int bc = -1;
+            for (int c = lane; c < nc; c += 64) {
+                const double d = cand[c].diff, a = cand[c].age;
+                const u64 o = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
+                if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = c; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const double od = __shfl_xor(bd, off), oa = __shfl_xor(ba, off);
+                const u64 oo = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(bo >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)bo, off);
+                const int oc = __shfl_xor(bc, off);
+                if (od > bd || (od == bd && (oa > ba || (oa == ba && oo < bo)))) { bd = od; ba = oa; bo = oo; bc = oc; }
+            }
+            bc = uni(bc);
+            if (bc < 0) break;
+            const double diff = cand[bc].diff;
+            const int idx = uni((int)cand[bc].idx), ch = uni((int)(cand[bc].chj & 0x1ff));
+            wave_sync();
+            if (lane == 0) cand[bc].diff = -1.0;
+            const OrlgPhySvc *r = grec + idx;
+            const int gid = uni((int)r->gid), nch = uni((int)r->nch);
+            const int mych = lane < nch ? (int)r->ch[lane] : 0xffff;
+            const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
+            if (jm) {
+                const int j = ctz64(jm);
+                const OrlgPathRec *rec = tb.recs + gid;
+                const int row = tb.pair_row[tb.path_pair[gid]];
+                // the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): right
+                // when both serve the same node pair, otherwise its loop runs out and leaves k - 1
+                const int base_cur = tb.pair_base[req_src * N + req_dst];
+                const int idp = (gid >= base_cur && gid < base_cur + K) ? gid - base_cur : K - 1;
+                const uint8_t *mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
+                const int level = uni((int)mrow[ch]);
+                const u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
+                int lv[W];
+                double mtr[W];
+                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, false, lv, mtr);
+#pragma unroll
+                for (int w = 0; w < W; ++w) lv[w] = lv[w] == level ? 0 : -1;
+                int l0, c0;
+                double m0;
+                phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
+                if (l0 >= 0 && -1.0 * m0 < diff) {
+                    // _move (:662-697)
+                    if (lane < rec->hops) {
+                        u64 *rowp = occ + (int)rec->link[lane] * W;
+                        rowp[c0 >> 6] &= ~(1ull << (c0 & 63));
+                        rowp[ch >> 6] |= 1ull << (ch & 63);
+                    }
+                    const int nxt = __shfl_down(mych, 1);
+                    int nv = mych;
+                    if (lane >= j && lane + 1 < nch) nv = nxt;
+                    if (lane == nch - 1) nv = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
+                    if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv;
+                    if (lane == 0) grec[idx].seq = (uint32_t)next_seq;
+                    next_seq += 1;
+                    cmoves += 1;
+                    wave_sync();
+                }
+            }
+            if (cmoves + gmoves > p.number_moves) break;
+        }
+        cycles = cmoves != 0 ? 1 : 0;
+    }
+    if (lane == 0) {
+        ws->counted_moves_groom = gmoves;
+        ws->counted_moves += cmoves;
+        ws->counted_defrag_cycles += cycles;
+        if (overflow) ws->q_overflow |= 2;
+    }
+    wave_sync();
+}
+
 template <int W>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -330,8 +638,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             ws->total_path_length = gs->total_path_length; ws->total_gsnr = gs->total_gsnr;
             ws->req_arrival = gs->req_arrival; ws->req_holding = gs->req_holding;
             ws->q_overflow = gs->q_overflow;
+            ws->counted_moves = gs->counted_moves; ws->counted_moves_groom = gs->counted_moves_groom;
+            ws->counted_defrag_cycles = gs->counted_defrag_cycles;
         }
     }
+    int next_seq = gs->next_seq;
+    OrlgPhyCand *gcand = p.cand ? p.cand + (size_t)env * p.cand_cap : nullptr;
     double current_time = gs->current_time;
     int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
@@ -421,7 +733,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         if (idp < K) {
                             int lv[W];
                             double mtr[W];
-                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, row, lane, metric_mode, flat, lv, mtr);
+                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr);
                             int bl, bc;
                             double bm;
                             phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
@@ -442,8 +754,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         if (best < 0) break;
                         int lv[W];
                         double mtr[W];
-                        phy_row_metrics<W>(occ, tb, p, acc, best, base + best, row, lane, metric_mode, flat, lv, mtr);
                         const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
+                        phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr);
                         int unassigned = demand;
                         nsel = 0;
                         bool covered = false;
@@ -496,14 +808,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         if (lane == 0) {
                             qtime[n_running] = ws->req_arrival + ws->req_holding;
                             OrlgPhySvc sv;
+                            sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
                             sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(1 | (dirbit ? 2 : 0));
                             for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
                                 sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) | (1 << 14)) : 0xffffu;
                             grec[n_running] = sv;
                         }
                         n_running += 1;
+                        next_seq += 1;
                     } else if (lane == 0) {
-                        ws->q_overflow = 1;
+                        ws->q_overflow |= 1;
                     }
                     wave_sync();
                 }
@@ -542,7 +856,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                             }
                         }
                         if (changed) cs_store(gcs, gcs_n, key, l, lane);
-                        if (overflow && lane == 0) ws->q_overflow = 1;
+                        if (overflow && lane == 0) ws->q_overflow |= 4;
                     }
                     // statistics, in channel order (the GSNR sum is a float64 accumulation)
                     if (lane == 0) {
@@ -564,6 +878,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         if (lane == 0) {
                             qtime[n_running] = ws->req_arrival + ws->req_holding;
                             OrlgPhySvc sv;
+                            sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
                             sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(dirbit ? 2 : 0);
                             for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
                                 sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) |
@@ -572,8 +887,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                             grec[n_running] = sv;
                         }
                         n_running += 1;
+                        next_seq += 1;
                     } else if (lane == 0) {
-                        ws->q_overflow = 1;
+                        ws->q_overflow |= 1;
                     }
                     wave_sync();
                 }
@@ -602,6 +918,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                         reinterpret_cast<int4 *>(tb.outs[ORLG_PHY_OUT_REQUEST])[o] = make_int4(req_sid, req_src, req_dst, demand);
                     if (om & (1 << ORLG_PHY_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_ARRIVAL])[o] = ws->req_arrival;
                     if (om & (1 << ORLG_PHY_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_HOLDING])[o] = ws->req_holding;
+                    if (om & (1 << ORLG_PHY_OUT_DEFRAG)) {  // the counters as the info dict sees them: before this step's defragmentation
+                        int32_t *od = reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_DEFRAG]) + o * 3;
+                        od[0] = ws->counted_moves; od[1] = ws->counted_moves_groom; od[2] = ws->counted_defrag_cycles;
+                    }
                     if (want_c) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_CUTS])[o] = cuts;
                     if (want_r) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
                 }
@@ -614,6 +934,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                 ws->c[2] = new_service ? 1 : 0; ws->c[3] = 0; ws->c[6] = new_service ? tb.bit_rates[req_br] : 0; ws->c[7] = 0;
                 ws->total_path_length = 0.0; ws->total_gsnr = 0.0; ws->total_path_index = 0; ws->total_mod = 0;
                 ws->channels_accepted = 0; ws->physical_accepted = 0;
+                ws->counted_moves = 0; ws->counted_moves_groom = 0; ws->counted_defrag_cycles = 0;
             }
             wave_sync();
         }
@@ -712,6 +1033,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             }
         }
 
+        if (p.mode == ORLG_MODE_STEP && p.defrag_period > 0) {
+            // periodic defragmentation (phy_rmsa_env.py:355-417): services_processed % defrag_period == 0
+            wave_sync();
+            const long long processed = ws->c[0];
+            if (processed % p.defrag_period == 0)
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, n_running, next_seq, current_time, req_src, req_dst, lane);
+        }
+
         if (p.mode == ORLG_MODE_STEP) {
             const bool done = (eproc == p.episode_length);
             if (lane == 0 && (p.out_mask & (1 << ORLG_PHY_OUT_DONE)))
@@ -723,6 +1052,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                     ws->c[2] = 1; ws->c[3] = 0; ws->c[6] = tb.bit_rates[req_br]; ws->c[7] = 0;
                     ws->total_path_length = 0.0; ws->total_gsnr = 0.0; ws->total_path_index = 0; ws->total_mod = 0;
                     ws->channels_accepted = 0; ws->physical_accepted = 0;
+                    ws->counted_moves = 0; ws->counted_moves_groom = 0; ws->counted_defrag_cycles = 0;
                 }
                 wave_sync();
             }
@@ -752,6 +1082,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             go->n_running = n_running;
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
+            go->next_seq = next_seq; go->counted_moves = ws->counted_moves; go->counted_moves_groom = ws->counted_moves_groom;
+            go->counted_defrag_cycles = ws->counted_defrag_cycles;
         }
     }
 }

@@ -6,8 +6,8 @@ reference's MATLAB object array).
 
 Device policies (``run(policy, ...)``): ``bmfa`` / ``bmfa_rss`` (``phy_rmsa_env.py:1375,1441``; they consult the
 virtual layer only when ``grooming=True``), ``sapff`` / ``bmff`` / ``sapbm`` (``:1676,1317,1254``; they always try
-``use_existing_channels`` first, like the reference) and ``external``.  Not built: the periodic defragmentation
-(``defrag_period`` raises NotImplementedError).
+``use_existing_channels`` first, like the reference) and ``external``.  ``defrag_period`` / ``number_moves`` / ``metric``
+switch on the periodic defragmentation (``phy_rmsa_env.py:355-417``), run inside the step kernel.
 """
 from __future__ import annotations
 
@@ -25,7 +25,9 @@ PHY_DEFAULT_BIT_RATES = (100, 200, 300, 400, 500, 600)  # phy_rmsa_env.py:38
 EPISODE_STATS_DTYPE = np.dtype([("total_path_length", np.float64), ("total_gsnr", np.float64),
                                 ("total_path_index", np.int64), ("total_modulation_level", np.int64),
                                 ("channels_accepted", np.int64), ("physical_services_accepted", np.int64),
-                                ("episodes_done", np.int64), ("queue_overflow", np.int64)])
+                                ("episodes_done", np.int64), ("queue_overflow", np.int64),
+                                ("counted_moves", np.int64), ("counted_moves_groom", np.int64),
+                                ("counted_defrag_cycles", np.int64)])
 
 
 def _pairs_from_connections_detail(cd):
@@ -55,9 +57,10 @@ class BatchedPhyRMSAEnv:
                  allow_rejection: bool = False, number_spectrum_channels: int = 80,
                  number_spectrum_channels_s_band: int = 108, l_band: bool = True, s_band: bool = True,
                  defrag_period=None, number_moves=None, metric: str = "cut", grooming: bool = False,
-                 queue_capacity: int = 0, channel_state_capacity: int = 0, device: int = 0, **_ignored):
-        if defrag_period:
-            raise NotImplementedError("periodic defragmentation is not on the device path yet")
+                 queue_capacity: int = 0, channel_state_capacity: int = 0, defrag_capacity: int = 0, device: int = 0,
+                 **_ignored):
+        if defrag_period and number_moves is None:
+            raise ValueError("defrag_period needs number_moves (the reference compares against it, phy_rmsa_env.py:358)")
         self.L = _lib.load()
         self.topology = FrozenTopology.from_graph(topology)
         t = self.topology
@@ -104,6 +107,9 @@ class BatchedPhyRMSAEnv:
         cc.k_table, cc.num_table_rows, cc.queue_capacity = mod.shape[2], mod.shape[0], int(queue_capacity)
         cc.grooming, cc.channel_state_capacity = (1 if grooming else 0), int(channel_state_capacity)
         self.grooming = bool(grooming)
+        cc.defrag_period, cc.number_moves = int(defrag_period or 0), int(number_moves or 0)
+        cc.defrag_metric, cc.defrag_capacity = (0 if metric == "cut" else 1), int(defrag_capacity)
+        self.defrag_period, self.number_moves, self.metric = defrag_period, number_moves, metric
         cc.arrival_lambda = 1 / self.mean_service_inter_arrival_time
         cc.holding_lambda = 1 / self.mean_service_holding_time
         cc.bit_rates = keep(self.bit_rates, np.int32)
@@ -154,7 +160,8 @@ class BatchedPhyRMSAEnv:
         res = {}
         for name in outputs:
             shape = {"request": (n_steps, B, 4), "channels": (n_steps, B, _lib.PHY_MAX_CHANNELS),
-                     "channels_used": (n_steps, B, _lib.PHY_MAX_CHANNELS)}.get(name, (n_steps, B))
+                     "channels_used": (n_steps, B, _lib.PHY_MAX_CHANNELS),
+                     "defrag_counters": (n_steps, B, 3)}.get(name, (n_steps, B))
             res[name] = np.zeros(shape, dtype=_lib.PHY_STEP_IO_DTYPES[name])
             setattr(io, name, _ptr(res[name]))
         ap = ac = None

@@ -1,6 +1,6 @@
 """Single-environment view of the QoT-aware environment with the reference's object surface.
 
-``PhyRMSAEnv`` is a drop-in for ``optical_rl_gym.envs.phy_rmsa_env.PhyRMSAEnv`` (physical and virtual layer, no
+``PhyRMSAEnv`` is a drop-in for ``optical_rl_gym.envs.phy_rmsa_env.PhyRMSAEnv`` (physical and virtual layer,
 periodic defragmentation): same constructor kwargs, ``step((path, channels))`` returning the reference's 5-tuple
 ``(obs, reward, done, False, info)`` with the same info keys (``phy_rmsa_env.py:319-348``), and the attributes / query
 methods its heuristic callbacks touch (``phy_rmsa_env.py:1254-1737``): ``is_channel_free``, ``calculate_r_cut``,
@@ -189,7 +189,7 @@ class PhyRMSAEnv:
         if path > 10:
             self.services_accepted_virtual += 1
         r = self._batched.run("external", 1, act_path=ap, act_channels=ac,
-                              outputs=("accepted", "done", "number_cuts_total", "rss_total_metric"))
+                              outputs=("accepted", "done", "number_cuts_total", "rss_total_metric", "defrag_counters"))
         served.accepted = bool(r["accepted"][0, 0])
         b = self._batched
         c = {k: int(v[0]) for k, v in b.counters().items()}
@@ -210,7 +210,8 @@ class PhyRMSAEnv:
             "number_cuts_total": float(r["number_cuts_total"][0, 0]),
             "rss_total_metric": float(r["rss_total_metric"][0, 0]),
             "total_path_length": float(st["total_path_length"]) / (phys + 1),
-            "num_moves": 0.0, "num_moves_groom": 0, "num_defrag_cycle": 0,
+            "num_moves": int(r["defrag_counters"][0, 0, 0]) / 2 + int(r["defrag_counters"][0, 0, 1]),
+            "num_moves_groom": int(r["defrag_counters"][0, 0, 1]), "num_defrag_cycle": int(r["defrag_counters"][0, 0, 2]),
             "avrage_gsnr": float(st["total_gsnr"]) / (chans + 1),
             # the reference's accumulator wraps at 256 under NumPy >= 2 (SURVEY 8c caveat 2); this is the true mean
             "average_mod_level": int(st["total_modulation_level"]) / (chans + 1),

@@ -281,7 +281,8 @@ PHY_POLICY = {"bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff
 
 class PhyConfig(C.Structure):
     _fields_ = [("num_channels", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
-                ("k_table", C.c_int32), ("grooming", C.c_int32), ("pad0", C.c_int32),
+                ("k_table", C.c_int32), ("grooming", C.c_int32), ("defrag_period", C.c_int32),
+                ("number_moves", C.c_int32), ("defrag_metric", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "link_ends", "path_node_off", "path_nodes")]
@@ -297,7 +298,8 @@ class PhyResult(C.Structure):
                [(n, C.c_double) for n in ("number_cuts_total", "rss_total_metric", "total_path_length", "avrage_gsnr",
                                           "average_path_index", "service_blocking_rate", "episode_service_blocking_rate",
                                           "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")] + \
-               [(n, C.c_int64) for n in ("total_modulation_level", "channels_accepted", "path_index", "physical_paths")]
+               [(n, C.c_int64) for n in ("total_modulation_level", "channels_accepted", "path_index", "physical_paths")] + \
+               [("num_moves", C.c_double), ("num_moves_groom", C.c_int64), ("num_defrag_cycle", C.c_int64)]
 
 
 PHY_TRACE_FIELDS = [
@@ -312,6 +314,7 @@ PHY_TRACE_FIELDS = [
     ("avrage_gsnr", np.float64, 1), ("average_path_index", np.float64, 1),
     ("episode_service_blocking_rate", np.float64, 1), ("bit_rate_blocking_rate", np.float64, 1),
     ("current_time", np.float64, 1),
+    ("num_moves", np.float64, 1), ("num_moves_groom", np.int64, 1), ("num_defrag_cycle", np.int64, 1),
 ]
 
 
@@ -345,7 +348,7 @@ class PhyOracleEnv:
 
     def __init__(self, tables, *, num_channels, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
                  arrival_lambda, holding_lambda, pair_table_row, modulation_level, gsnr, link_ends, path_node_off,
-                 path_nodes, grooming=False, seed=41, asan=False):
+                 path_nodes, grooming=False, defrag_period=None, number_moves=None, metric="cut", seed=41, asan=False):
         self.L = _phy_lib(asan)
         self._keep = []
 
@@ -365,6 +368,9 @@ class PhyOracleEnv:
         c.num_channels, c.episode_length, c.num_bit_rates = int(num_channels), int(episode_length), len(bit_rates)
         c.k_table = int(np.asarray(modulation_level).shape[2])
         c.grooming = 1 if grooming else 0
+        c.defrag_period = int(defrag_period or 0)
+        c.number_moves = int(number_moves or 0)
+        c.defrag_metric = 0 if metric == "cut" else 1
         c.arrival_lambda, c.holding_lambda = float(arrival_lambda), float(holding_lambda)
         c.bit_rates = keep(bit_rates, np.int32)
         c.bit_rate_cum = keep(bit_rate_cum, np.float64)

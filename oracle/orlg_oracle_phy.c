@@ -51,6 +51,7 @@ struct orc_phy_env {
     pevent *heap;
     int n_heap, cap_heap;
     int64_t seq;
+    int64_t counted_moves, counted_moves_groom, counted_defrag_cycles;  /* phy_rmsa_env.py:110-112 */
     cs_list *cs;        /* [N*N*K] */
     uint8_t *col, *col2;
     int *r_start, *r_len;
@@ -91,14 +92,15 @@ static int is_channel_free(const orc_phy_env *e, int gid, int ch) {
 
 /* phy_rmsa_env.py:1123-1193, modified=True, defrag_flag=False: cuts against the links adjacent to the
  * path's nodes before minus after taking the channel on the path's links */
-static int r_cut_modified(orc_phy_env *e, int gid, int ch) {
+static int r_cut_modified_flag(orc_phy_env *e, int gid, int ch, int defrag_flag) {
     const int32_t *nodes = e->cfg.path_nodes + e->cfg.path_node_off[gid];
     int nn = e->cfg.path_node_off[gid + 1] - e->cfg.path_node_off[gid];
     int before = 0, after = 0;
     for (int pass = 0; pass < 2; pass++) {
         column(e, ch, e->col);
         if (pass == 1)
-            for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++) e->col[e->topo.path_links[h]] = 0;
+            for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+                e->col[e->topo.path_links[h]] = defrag_flag ? 1 : 0;
         int acc = 0;
         for (int i = 0; i < nn; i++) {
             for (int nk = 0; nk < e->N; nk++) {
@@ -122,6 +124,8 @@ static int r_cut_modified(orc_phy_env *e, int gid, int ch) {
     return before - after;
 }
 
+static int r_cut_modified(orc_phy_env *e, int gid, int ch) { return r_cut_modified_flag(e, gid, ch, 0); }
+
 static double rss_of_column(orc_phy_env *e, const uint8_t *col) {
     int runs = prle(col, e->E, e->r_start, e->r_val, e->r_len);
     int64_t sq = 0, sm = 0;
@@ -130,15 +134,17 @@ static double rss_of_column(orc_phy_env *e, const uint8_t *col) {
     return sqrt((double)sq) / (double)(sm + 1);
 }
 
-/* phy_rmsa_env.py:1085-1108, defrag_flag=False */
-static double r_spatial(orc_phy_env *e, int gid, int ch) {
+/* phy_rmsa_env.py:1085-1108 */
+static double r_spatial_flag(orc_phy_env *e, int gid, int ch, int defrag_flag) {
     column(e, ch, e->col);
     double r0 = 0 + rss_of_column(e, e->col);
     memcpy(e->col2, e->col, e->E);
-    for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++) e->col2[e->topo.path_links[h]] = 0;
+    for (int h = e->topo.path_link_off[gid]; h < e->topo.path_link_off[gid + 1]; h++)
+        e->col2[e->topo.path_links[h]] = defrag_flag ? 1 : 0;
     double r1 = 0 + rss_of_column(e, e->col2);
     return r1 - r0;
 }
+static double r_spatial(orc_phy_env *e, int gid, int ch) { return r_spatial_flag(e, gid, ch, 0); }
 
 /* phy_rmsa_env.py:1195-1203 */
 static double total_cuts(orc_phy_env *e) {
@@ -261,6 +267,7 @@ void orc_phy_reset(orc_phy_env *e, int only_episode_counters) {
     e->total_path_length_episode = 0; e->total_path_index_episode = 0; e->total_gsnr_episode = 0;
     e->total_modulation_level_episode = 0; e->channels_accepted_episode = 0;
     e->physical_services_accepted_episode = 0;
+    e->counted_defrag_cycles = 0; e->counted_moves = 0; e->counted_moves_groom = 0;
     if (only_episode_counters) {
         if (e->new_service) {
             e->c.episode_services_processed += 1;
@@ -338,6 +345,8 @@ static int cmp_level_ch(const void *a, const void *b) { /* key (-x[0], x[1]) */
     if (x->key0 != y->key0) return x->key0 < y->key0 ? -1 : 1;
     return x->ch - y->ch;
 }
+
+static void running_add(orc_phy_env *e, pservice *s);
 
 /* use_existing_channels (phy_rmsa_env.py:1650-1673): residual capacity of partially used channels between the
  * same (source, destination, k-path); returns 1 and fills act (path = idp + 20) when the request fits */
@@ -453,7 +462,125 @@ static void running_add(orc_phy_env *e, pservice *s) {
     e->running[e->n_running++] = s;
 }
 
-/* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424) without the periodic defragmentation */
+static void running_remove(orc_phy_env *e, pservice *s) {
+    for (int i = 0; i < e->n_running; i++)
+        if (e->running[i] == s) {
+            memmove(&e->running[i], &e->running[i + 1], sizeof(pservice *) * (e->n_running - i - 1));
+            e->n_running--;
+            return;
+        }
+}
+/* service.channels.remove(channel j); service.channels.append((ch, used, ..., cap, ...)) */
+static void channels_move(pservice *s, int j, int ch, int used, int cap) {
+    for (int q = j; q + 1 < s->nch; q++) { s->ch[q] = s->ch[q + 1]; s->used[q] = s->used[q + 1]; s->cap[q] = s->cap[q + 1]; }
+    s->ch[s->nch - 1] = ch; s->used[s->nch - 1] = used; s->cap[s->nch - 1] = cap;
+}
+
+/* _groom_defragmentation (phy_rmsa_env.py:703-733) + _move_virtual (:735-764).  The two for loops run over Python
+ * lists that the body mutates (remove + append): an index-based walk over the live arrays is exactly the list
+ * iterator's behaviour (the element after a moved one is skipped, the moved one is met again at the end). */
+static int groom_defragmentation(orc_phy_env *e) {
+    int moves = 0;
+    for (int i = 0; i < e->n_running; i++) {
+        pservice *s = e->running[i];
+        for (int j = 0; j < s->nch; j++) {
+            if (s->used[j] != s->cap[j]) {
+                cs_list *l = cs_of(e, s->src, s->dst, s->idp);
+                const cs_entry corr = l->e[cs_find(l, s->ch[j])];
+                if (corr.used == s->used[j]) {  /* this service is the channel's only user */
+                    for (int t = 0; t < l->n; t++) {
+                        const cs_entry tg = l->e[t];
+                        if (tg.ch != corr.ch && tg.free_ >= s->used[j]) {
+                            const int share = s->used[j];
+                            cs_remove(l, t);
+                            cs_remove(l, cs_find(l, corr.ch));
+                            cs_entry up = { tg.ch, tg.used + share, tg.free_ - share, tg.cap };
+                            cs_append(l, up);
+                            free_channel_on_path(e, s->path_gid, s->ch[j]);
+                            running_remove(e, s);
+                            channels_move(s, j, tg.ch, share, tg.cap);
+                            running_add(e, s);
+                            moves++;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (moves == e->cfg.number_moves) return moves;
+        }
+    }
+    return moves;
+}
+
+typedef struct { double diff, age; pservice *svc; int ch, order; } dcand;
+static int cmp_dcand(const void *a, const void *b) { /* key (-x[0], -x[1]); stable */
+    const dcand *x = (const dcand *)a, *y = (const dcand *)b;
+    if (x->diff != y->diff) return x->diff > y->diff ? -1 : 1;
+    if (x->age != y->age) return x->age > y->age ? -1 : 1;
+    return x->order - y->order;
+}
+
+/* the periodic defragmentation block of step (phy_rmsa_env.py:355-417) + _move (:662-697) */
+static void periodic_defragmentation(orc_phy_env *e) {
+    const int rss = e->cfg.defrag_metric == 1;
+    e->counted_moves_groom = groom_defragmentation(e);
+    if (e->counted_moves_groom > e->cfg.number_moves) return;
+    int total = 0;
+    for (int i = 0; i < e->n_running; i++) total += e->running[i]->nch;
+    dcand *cands = (dcand *)malloc(sizeof(dcand) * (size_t)(total + 1));
+    int nc = 0;
+    for (int i = 0; i < e->n_running; i++) {
+        pservice *s = e->running[i];
+        for (int j = 0; j < s->nch; j++)
+            if (s->used[j] == s->cap[j]) {  /* only channels the service fills are reallocated */
+                double diff = rss ? r_spatial_flag(e, s->path_gid, s->ch[j], 1) : (double)r_cut_modified_flag(e, s->path_gid, s->ch[j], 1);
+                if (diff > 0) {
+                    dcand c = { diff, e->current_time - s->arrival_time, s, s->ch[j], nc };
+                    cands[nc++] = c;
+                }
+            }
+    }
+    qsort(cands, nc, sizeof(dcand), cmp_dcand);
+    int num_moves = 0;
+    const pservice *cur = e->current;
+    for (int q = 0; q < nc; q++) {
+        pservice *s = cands[q].svc;
+        const int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
+        /* the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): the
+         * index is right when both serve the same node pair, otherwise the loop runs out and leaves k - 1 */
+        int idp = e->K - 1;
+        for (int k = 0; k < e->K; k++)
+            if (ppath_gid(e, cur->src, cur->dst, k) == s->path_gid) { idp = k; break; }
+        const int level = e->cfg.modulation_level[((size_t)row * e->C + cands[q].ch) * e->cfg.k_table + idp];
+        int have = 0, best_ch = -1;
+        double best_m = 0;
+        for (int ch = 0; ch < e->C; ch++)
+            if (is_channel_free(e, s->path_gid, ch) &&
+                e->cfg.modulation_level[((size_t)row * e->C + ch) * e->cfg.k_table + idp] == level) {
+                double m = rss ? r_spatial(e, s->path_gid, ch) : (double)r_cut_modified(e, s->path_gid, ch);
+                if (!have || m > best_m) { have = 1; best_m = m; best_ch = ch; }  /* sorted by (-metric, channel) */
+            }
+        if (have && -1 * best_m < cands[q].diff) {
+            /* _move: the channel list entry is found by value (channel numbers are unique within a service) */
+            int j = 0;
+            while (j < s->nch && s->ch[j] != cands[q].ch) j++;
+            for (int h = e->topo.path_link_off[s->path_gid]; h < e->topo.path_link_off[s->path_gid + 1]; h++) {
+                e->avail[(size_t)e->topo.path_links[h] * e->C + best_ch] = 0;
+                e->avail[(size_t)e->topo.path_links[h] * e->C + cands[q].ch] = 1;
+            }
+            running_remove(e, s);
+            channels_move(s, j, best_ch, s->used[j], s->cap[j]);
+            running_add(e, s);
+            num_moves++;
+            e->counted_moves++;
+        }
+        if (num_moves + e->counted_moves_groom > e->cfg.number_moves) break;
+    }
+    if (num_moves != 0) e->counted_defrag_cycles++;
+    free(cands);
+}
+
+/* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424) */
 void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out) {
     pservice *s = e->current;
     s->accepted = 0; s->virtual_layer = 0;
@@ -529,9 +656,13 @@ void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out
         out->average_path_index = (double)e->total_path_index_episode / (double)(e->physical_services_accepted_episode + 1);
         out->path_index = e->total_path_index_episode;
         out->physical_paths = e->physical_services_accepted_episode;
+        out->num_moves = (double)e->counted_moves / 2 + (double)e->counted_moves_groom;
+        out->num_moves_groom = e->counted_moves_groom;
+        out->num_defrag_cycle = e->counted_defrag_cycles;
     }
     e->new_service = 0;
     next_service(e);
+    if (e->cfg.defrag_period > 0 && e->c.services_processed % e->cfg.defrag_period == 0) periodic_defragmentation(e);
     if (out) out->done = (e->c.episode_services_processed == e->cfg.episode_length);
 }
 
@@ -587,6 +718,9 @@ void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done,
             if (tr->episode_service_blocking_rate) tr->episode_service_blocking_rate[i] = r.episode_service_blocking_rate;
             if (tr->bit_rate_blocking_rate) tr->bit_rate_blocking_rate[i] = r.bit_rate_blocking_rate;
             if (tr->current_time) tr->current_time[i] = e->current_time;
+            if (tr->num_moves) tr->num_moves[i] = r.num_moves;
+            if (tr->num_moves_groom) tr->num_moves_groom[i] = r.num_moves_groom;
+            if (tr->num_defrag_cycle) tr->num_defrag_cycle[i] = r.num_defrag_cycle;
             if (tr->n_running) tr->n_running[i] = e->n_running;
             if (tr->free_total) {
                 int64_t f = 0;

@@ -18,7 +18,9 @@ typedef struct orc_phy_config {
     int32_t num_bit_rates;
     int32_t k_table;        /* number of k-path columns in the QoT tables */
     int32_t grooming;       /* env.grooming (phy_rmsa_env.py:57): consulted by bmfa / bmfa_rss only */
-    int32_t pad0;
+    int32_t defrag_period;  /* phy_rmsa_env.py:54: 0 = no periodic defragmentation */
+    int32_t number_moves;   /* phy_rmsa_env.py:55 */
+    int32_t defrag_metric;  /* env.metric (phy_rmsa_env.py:56): 0 = 'cut', 1 = anything else (RSS) */
     double arrival_lambda, holding_lambda;
     const int32_t *bit_rates;
     const double *bit_rate_cum, *src_cum, *dst_cum;
@@ -47,6 +49,8 @@ typedef struct orc_phy_result {
     double service_blocking_rate, episode_service_blocking_rate, bit_rate_blocking_rate,
         episode_bit_rate_blocking_rate;
     int64_t total_modulation_level, channels_accepted, path_index, physical_paths;
+    double num_moves;       /* counted_moves / 2 + counted_moves_groom (phy_rmsa_env.py:340) */
+    int64_t num_moves_groom, num_defrag_cycle;
 } orc_phy_result;
 
 typedef struct orc_phy_trace {
@@ -57,6 +61,8 @@ typedef struct orc_phy_trace {
         *n_running, *free_total;
     double *number_cuts_total, *rss_total_metric, *total_path_length, *avrage_gsnr, *average_path_index,
         *episode_service_blocking_rate, *bit_rate_blocking_rate, *current_time;
+    double *num_moves;
+    int64_t *num_moves_groom, *num_defrag_cycle;
 } orc_phy_trace;
 
 typedef struct orc_phy_env orc_phy_env;

@@ -433,10 +433,11 @@ def run_phy_trace(topo, tables, env_kwargs, policy, n_steps, reset_on_done):
     for _ in range(n_steps):
         s = env.current_service
         a = pol(env)
+        chosen = [tuple(c) for c in a[1]]  # the env keeps (and, when defragmenting, rewrites) the list object itself
         _, reward, done, _, info = env.step(a)
         row_c, row_u, row_f, row_k = [-1] * MAXCH, [0.0] * MAXCH, [0.0] * MAXCH, [0] * MAXCH
-        assert len(a[1]) <= MAXCH
-        for i, c in enumerate(a[1]):
+        assert len(chosen) <= MAXCH
+        for i, c in enumerate(chosen):
             row_c[i], row_u[i], row_f[i], row_k[i] = int(c[0]), float(c[1]), float(c[2]), int(c[3])
         chans.append(row_c); used.append(row_u); free.append(row_f); cap.append(row_k)
         av = env.topology.graph["available_channels"]
@@ -456,6 +457,8 @@ def run_phy_trace(topo, tables, env_kwargs, policy, n_steps, reset_on_done):
             bit_rate_blocking_rate=float(info["bit_rate_blocking_rate"]),
             free_total=int(av.sum()), occ_crc=occ_crc(av), current_time=env.current_time,
             n_running=len(env.topology.graph["running_services"]),
+            num_moves=float(info["num_moves"]), num_moves_groom=int(info["num_moves_groom"]),
+            num_defrag_cycle=int(info["num_defrag_cycle"]),
         )
         if done and reset_on_done:
             env.reset()
@@ -489,16 +492,24 @@ PHY_CASES = [
     ("phy_us14_s13_bmfa_rss_groom_load3000", "us14_k3", dict(seed=13, load=3000, grooming=True), "bmfa_rss", 1200, True),
     ("phy_us14_s14_sapff_load4000", "us14_k3", dict(seed=14, load=4000), "sapff", 2600, True),  # reaches blocking
     ("phy_jpn12_s5_bmff", "jpn12_k3", dict(seed=5, load=900), "bmff", 800, True),
+    # periodic defragmentation (tests/test_rmsa_threads_us.py:190-251: defrag_period=10, number_moves=10, cut / rss)
+    ("phy_us14_s10_bmfa_defrag_cut", "us14_k3", dict(defrag_period=10, number_moves=10), "bmfa", 600, True),
+    ("phy_us14_s10_bmfa_rss_defrag_rss", "us14_k3", dict(defrag_period=10, number_moves=10, metric="rss"), "bmfa_rss", 450, True),
+    ("phy_us14_s16_sapff_defrag_load3000", "us14_k3", dict(seed=16, load=3000, defrag_period=10, number_moves=10), "sapff", 700, True),
+    ("phy_jpn12_s7_bmff_defrag_rss", "jpn12_k3", dict(seed=7, load=900, defrag_period=7, number_moves=4, metric="rss"), "bmff", 500, True),
     # fragmentation-aware first fit (tests/test_rmsa_threads_us.py:87-108)
     ("phy_us14_s10_faff", "us14_k3", dict(), "faff", 600, True),
     ("phy_us14_s15_faff_rss_load2400", "us14_k3", dict(seed=15, load=2400), "faff_rss", 800, True),
 ]
 
 
-def gen_phy(only_missing=False):
-    gen_phy_tables()
+def gen_phy(only_missing=False, only_case=None):
+    if only_case is None:
+        gen_phy_tables()
     for name, tab, over, policy, steps, reset in PHY_CASES:
         if only_missing and os.path.exists(os.path.join(HERE, name + ".npz")):
+            continue
+        if only_case is not None and name != only_case:
             continue
         kw = dict(PHY_BASE)
         kw.update(over)
@@ -606,6 +617,7 @@ def gen_osnr():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--case", default=None, help="with --only phy: one PHY_CASES entry")
     args = ap.parse_args()
     install_gym_stub()
     import optical_rl_gym  # noqa: F401  (registers env ids)
@@ -613,6 +625,9 @@ def main():
     todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "deeprmsa", "phy", "osnr"]
     for what in todo:
         fn = globals().get("gen_" + what)
+        if what == "phy" and args.case:
+            gen_phy(only_case=args.case)
+            continue
         if fn is None:
             print("skip", what, "(generator not implemented yet)")
             continue

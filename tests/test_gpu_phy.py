@@ -9,7 +9,7 @@ from test_gpu_rmsa import device_log_in_oracle  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 OUTS = ("act_path", "n_channels", "channels", "channels_used", "accepted", "done", "request", "arrival", "holding",
-        "number_cuts_total", "rss_total_metric")
+        "number_cuts_total", "rss_total_metric", "defrag_counters")
 
 
 def make_env(topo, tables, kw, batch, **extra):
@@ -25,7 +25,9 @@ def make_env(topo, tables, kw, batch, **extra):
                                        ("phy_us14_s10_sapbm", 800), ("phy_us14_s11_bmfa_load2400", 1500),
                                        ("phy_us14_s10_bmfa_groom", 800), ("phy_us14_s13_bmfa_rss_groom_load3000", 1200),
                                        ("phy_us14_s14_sapff_load4000", 2600), ("phy_jpn12_s5_bmff", 800),
-                                       ("phy_us14_s10_faff", 600), ("phy_us14_s15_faff_rss_load2400", 800)])
+                                       ("phy_us14_s10_faff", 600), ("phy_us14_s15_faff_rss_load2400", 800),
+                                       ("phy_us14_s10_bmfa_defrag_cut", 600), ("phy_us14_s10_bmfa_rss_defrag_rss", 450),
+                                       ("phy_us14_s16_sapff_defrag_load3000", 700), ("phy_jpn12_s7_bmff_defrag_rss", 500)])
 def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     z, meta = load_golden(case)
     topo = load_topology(meta["topology"])
@@ -49,6 +51,9 @@ def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
         for f in ("arrival", "holding", "number_cuts_total", "rss_total_metric"):
             bad = np.nonzero(tr[f][:, i] != ot[f])[0]
             assert bad.size == 0, (f, i, bad[:4], tr[f][bad[:4], i], ot[f][bad[:4]])
+        dc = tr["defrag_counters"][:, i].astype(np.int64)
+        assert np.array_equal(dc[:, 1], ot["num_moves_groom"]) and np.array_equal(dc[:, 2], ot["num_defrag_cycle"]), i
+        assert np.array_equal(dc[:, 0] / 2 + dc[:, 1], ot["num_moves"]), i
         oc = o.counters()
         for name in oc:
             assert cnt[name][i] == oc[name], (name, i)
@@ -68,6 +73,10 @@ def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     assert np.array_equal(tr["number_cuts_total"][:, 0], z["number_cuts_total"][:n])
     assert np.array_equal(tr["rss_total_metric"][:, 0], z["rss_total_metric"][:n])
     assert cnt["services_accepted"][0] == z["services_accepted"][n - 1]
+    if "num_moves" in z.files:
+        dc = tr["defrag_counters"][:, 0].astype(np.int64)
+        assert np.array_equal(dc[:, 0] / 2 + dc[:, 1], z["num_moves"][:n])
+        assert np.array_equal(dc[:, 1], z["num_moves_groom"][:n]) and np.array_equal(dc[:, 2], z["num_defrag_cycle"][:n])
     env.close()
 
 

@@ -37,7 +37,8 @@ def test_phy_view_bmfa_matches_reference():
                                               ("phy_us14_s10_sapbm", "phy_aware_sapbm_rmsa", 120),
                                               ("phy_us14_s10_bmfa_groom", "phy_aware_bmfa_rmsa", 120),
                                               ("phy_us14_s10_bmfa_rss", "phy_aware_bmfa_rss_rmsa", 60),
-                                              ("phy_us14_s10_faff", "phy_aware_faff_rmsa", 80)])
+                                              ("phy_us14_s10_faff", "phy_aware_faff_rmsa", 80),
+                                              ("phy_us14_s10_bmfa_defrag_cut", "phy_aware_bmfa_rmsa", 130)])
 def test_phy_view_heuristics_with_virtual_layer(case, heuristic, n):
     """The heuristic callbacks on the single-env view (incl. use_existing_channels on env.channel_state and virtual-layer
     actions path = 20 + k-path) reproduce the reference's trace."""
@@ -57,6 +58,9 @@ def test_phy_view_heuristics_with_virtual_layer(case, heuristic, n):
         assert reward == z["reward"][t] and done == bool(z["done"][t])
         assert info["number_cuts_total"] == z["number_cuts_total"][t]
         assert info["physical_paths"] == z["physical_paths"][t]
+        if "num_moves" in z.files:
+            assert info["num_moves"] == z["num_moves"][t] and info["num_moves_groom"] == z["num_moves_groom"][t]
+            assert info["num_defrag_cycle"] == z["num_defrag_cycle"][t]
         if done:
             env.reset()
     env.close()
