@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liborlg.so")
+LIB_PATH = os.environ.get("ORLG_LIB_PATH") or os.path.join(HERE, "liborlg.so")  # ORLG_LIB_PATH: debug builds (tools/)
 
 ORLG_OK = 0
 ERR_NAMES = {-1: "ORLG_ERR_INVALID", -2: "ORLG_ERR_NO_DEVICE", -3: "ORLG_ERR_HIP", -4: "ORLG_ERR_QUEUE_FULL"}
@@ -81,7 +81,7 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    if build_if_missing and not os.environ.get("ORLG_LIB_PATH"):
         from . import build as _build
         if _build.needs_build():
             _build.build(verbose=False)

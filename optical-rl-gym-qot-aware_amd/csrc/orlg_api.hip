@@ -40,6 +40,8 @@ struct orlg_env {
     bool own_stream;
     size_t lds_block_bytes;
     int waves_per_block;
+    int resident_blocks;   // workgroups of the step kernel the device keeps resident (grid size of the work queue)
+    uint32_t ticket_base;
     int num_paths;
     // owned device buffers
     std::vector<void *> bufs;
@@ -219,8 +221,20 @@ static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
     const int wpb = e->waves_per_block;
-    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
-    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, p);
+    if (e->resident_blocks <= 0) {
+        int nb = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->lds_block_bytes));
+        e->resident_blocks = (nb > 0 ? nb : 1) * prop.multiProcessorCount;
+    }
+    int nblocks = (p.B + wpb - 1) / wpb;
+    if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
+    OrlgParams q = p;
+    q.ticket_base = e->ticket_base;
+    e->ticket_base += (uint32_t)p.B + (uint32_t)(nblocks * wpb);  // every wave draws one ticket beyond its last environment
+    dim3 grid(nblocks), block(ORLG_WAVE * wpb);
+    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     return ORLG_OK;
 }
@@ -319,6 +333,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     orlg_env *e = new orlg_env();
     memset(&e->p, 0, sizeof(e->p));
     e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
+    e->resident_blocks = 0; e->ticket_base = 0;
     e->d_actions = nullptr; e->d_actions_cap = 0; e->num_paths = t->num_paths;
     for (int i = 0; i < 12; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -432,6 +447,11 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     TRY(dev_alloc(e, &p.qdesc, (size_t)batch * Q));
     TRY(dev_alloc(e, &p.mt, (size_t)batch * ORLG_MT_N));
     TRY(dev_alloc(e, &p.scal, (size_t)batch));
+    TRY(dev_alloc(e, &p.ticket, (size_t)4));
+    {
+        hipError_t er = hipMemset(p.ticket, 0, 16);
+        if (er != hipSuccess) { orlg_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(er)); }
+    }
     TRY(dev_alloc(e, &p.hist, (size_t)batch * 4 * NBR));
     TRY(dev_alloc(e, &p.lstat, (size_t)batch * 4 * E));
     TRY(dev_alloc(e, &p.ring_iat, (size_t)batch * ORLG_RING));
@@ -749,5 +769,13 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
 
 }  // extern "C"
 
+#ifdef ORLG_SECTIONS
+extern "C" int orlg_debug_sections(unsigned long long *out, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(orlg_sections), 16 * 8));
+    if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(orlg_sections), z, 16 * 8)); }
+    return ORLG_OK;
+}
+#endif
 #include "orlg_phy_api.hip"
 #include "orlg_osnr.hip"

@@ -90,6 +90,10 @@ struct OrlgParams {
     const int32_t *actions;
     void *outs[ORLG_NUM_OUTS];
     double *o_obs;
+    // work queue: every wave draws environments from *ticket until the launch's B are taken (ticket - ticket_base
+    // is the environment index; the host advances ticket_base by B + launched waves per launch, no memset needed)
+    uint32_t *ticket;
+    uint32_t ticket_base, pad_ticket;
     // per-wave LDS layout (byte offsets from the wave's base) and size
     int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_ring, l_wave_bytes;
     int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions

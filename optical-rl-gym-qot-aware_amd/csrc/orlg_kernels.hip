@@ -546,6 +546,22 @@ DEV void apply_window(Wave &wv, const uint8_t *links, int hops, int s, int n, bo
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------------------- section timing (debug builds)
+// -DORLG_SECTIONS: wall cycles each wave spends in the sections of a step, summed over all waves into orlg_sections[]
+// (tools/section_profile.py).  Not compiled into the product library.
+#ifdef ORLG_SECTIONS
+__device__ unsigned long long orlg_sections[16];
+#define SEC_DECL __shared__ unsigned long long sec_acc[ORLG_MAX_WAVES_PER_BLOCK][16]; long long sec_t0 = 0; int sec_cur = 0; \
+    if (lane < 16) sec_acc[wib][lane] = 0ull; wave_sync(); sec_t0 = __builtin_readcyclecounter();
+#define SEC(i) do { const long long sec_n = __builtin_readcyclecounter(); if (lane == 0) sec_acc[wib][sec_cur] += (unsigned long long)(sec_n - sec_t0); \
+    sec_t0 = sec_n; sec_cur = (i); } while (0)
+#define SEC_FLUSH do { SEC(0); wave_sync(); if (lane < 16) atomicAdd(&orlg_sections[lane], sec_acc[wib][lane]); } while (0)
+#else
+#define SEC_DECL
+#define SEC(i) do { } while (0)
+#define SEC_FLUSH do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------- the step kernel
 template <int W, int STATS>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
@@ -553,8 +569,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
-    const int env = blockIdx.x * (int)(blockDim.x >> 6) + wib;
-    if (env >= p.B) return;
     const Tab tb = make_tab(smem, p);
     unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * p.l_wave_bytes;
     Wave wv;
@@ -575,7 +589,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     constexpr bool NET = STATS >= 1;
     constexpr bool FULL = STATS >= 2;
+    SEC_DECL
 
+    // ------------------------------------------------------------------ work queue: one environment at a time per wave
+    // (a wave that finishes early takes the next environment instead of idling until its workgroup drains; every
+    // wave leaves through the same exit: the first ticket at or beyond B)
+    for (;;) {
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(kernarg_params()->ticket, 1u) - p.ticket_base;
+    const int env = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    if ((uint32_t)env >= (uint32_t)p.B) break;
+    SEC(1);  // state load
     // ------------------------------------------------------------------ HBM -> LDS (coalesced)
     {
         const u64 *g = p.occ + (size_t)env * NW;
@@ -625,6 +649,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
 
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
+        SEC(2);  // policy
         if (p.mode == ORLG_MODE_STEP) {
             // ========================================================== policy: pick (path, slot)
             const int base = tb.pair_base[req_src * N + req_dst];
@@ -694,6 +719,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             }
 
             // ========================================================== RMSAEnv.step (rmsa_env.py:222-341)
+            SEC(3);  // validate + provision
             const double prev_compact = comp_cur;
             bool accepted = false;
             if (a_path >= 0 && a_path < K && a_slot >= 0 && a_slot < S) {
@@ -718,6 +744,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                         wv.hist[NBR + req_br] += 1;
                         wv.hist[3 * NBR + req_br] += 1;
                     }
+                    SEC(4);  // statistics at provision
                     if (NET) {
                         wave_sync();
                         cur_thr = (double)wv.wsc->sum_bitrate_running;
@@ -726,6 +753,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                                                          comp_cur, sum_sh, cur_thr);
                     }
                     accepted = true;
+                    SEC(5);  // queue insert
                     // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
                     double rel = wv.wsc->req_arrival + wv.wsc->req_holding;
                     bool placed = false;
@@ -745,6 +773,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                 }
             }
 
+            SEC(6);  // outputs
             // per-step outputs (lane 0; consecutive envs are consecutive addresses)
             if (p.out_mask) {
                 const size_t o = (size_t)t * p.B + env;
@@ -792,11 +821,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
         }
 
         // ============================================================== _next_service (rmsa_env.py:643-695)
+        SEC(7);  // next arrival
         if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
             if (ring_cnt == 0) {
+                SEC(8);  // refill
                 ring_cnt = refill_requests(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
                                            &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda);
                 ring_pos = 0;
+                SEC(7);
             }
             const double at = current_time + wv.ring_iat[ring_pos];
             const double ht = wv.ring_ht[ring_pos];
@@ -820,6 +852,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
             bool released = false;
             for (;;) {
+                SEC(9);  // release scan
                 double best_t = 0.0;
                 int best_q = -1;
                 for (int q0 = 0; q0 < Q; q0 += 64) {
@@ -833,6 +866,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                     }
                 }
                 if (best_q < 0) break;
+                SEC(10);  // release apply
                 // ---- _release_path (rmsa_env.py:515-535)
                 const uint32_t d = wv.qdesc[best_q];
                 const int gid = (int)(d & 0x3fff), s0 = (int)((d >> 14) & 0x3ff), bri2 = (int)(d >> 24);
@@ -846,6 +880,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
                 }
                 apply_window<W>(wv, rec->link, hops, s0, n, true);
                 sum_sh -= n * hops;
+                SEC(11);  // statistics at release
                 if (NET)
                     link_stats_update<W, FULL, false>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
                                                       comp_cur, sum_sh, 0.0);
@@ -854,6 +889,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
         }
 
+        SEC(12);  // done / episode reset
         if (p.mode == ORLG_MODE_STEP) {
             const bool done = (eproc == p.episode_length);
             if (lane == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
@@ -875,6 +911,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     }
 
     // ------------------------------------------------------------------ LDS -> HBM (coalesced)
+    SEC(13);  // state store
     wave_sync();
     {
         KernargParams kp = kernarg_params();
@@ -909,6 +946,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
         }
     }
+    wave_sync();
+    SEC(0);
+    }  // work queue
+    SEC_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------- queries

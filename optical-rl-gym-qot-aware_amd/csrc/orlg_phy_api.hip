@@ -4,7 +4,8 @@
 
 struct orlg_phy_env {
     OrlgPhyParams p;
-    int W, device, waves_per_block, num_paths;
+    int W, device, waves_per_block, num_paths, resident_blocks;
+    uint32_t ticket_base;
     hipStream_t stream;
     bool own_stream;
     size_t lds_block_bytes;
@@ -102,8 +103,20 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
     const int wpb = e->waves_per_block;
-    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
-    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, p);
+    if (e->resident_blocks <= 0) {
+        int nb = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->lds_block_bytes));
+        e->resident_blocks = (nb > 0 ? nb : 1) * prop.multiProcessorCount;
+    }
+    int nblocks = (p.B + wpb - 1) / wpb;
+    if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
+    OrlgPhyParams q = p;
+    q.ticket_base = e->ticket_base;
+    e->ticket_base += (uint32_t)p.B + (uint32_t)(nblocks * wpb);
+    dim3 grid(nblocks), block(ORLG_WAVE * wpb);
+    hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     return ORLG_OK;
 }
@@ -178,6 +191,7 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     memset(&e->p, 0, sizeof(e->p));
     e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
     e->d_act_path = nullptr; e->d_act_ch = nullptr; e->num_paths = t->num_paths;
+    e->resident_blocks = 0; e->ticket_base = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
@@ -337,6 +351,11 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     TRY(alloc(reinterpret_cast<void **>(&p.scal), (size_t)batch * sizeof(OrlgPhyScalars)));
     TRY(alloc(reinterpret_cast<void **>(&p.cs), (size_t)batch * N * N * K * p.cs_len * 4));
     TRY(alloc(reinterpret_cast<void **>(&p.cs_n), (size_t)batch * N * N * K));
+    TRY(alloc(reinterpret_cast<void **>(&p.ticket), 16));
+    {
+        hipError_t er = hipMemset(p.ticket, 0, 16);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(er)); }
+    }
     if (p.defrag_period > 0) {
         // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
         p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;

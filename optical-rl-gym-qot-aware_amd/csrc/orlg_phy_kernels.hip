@@ -75,6 +75,8 @@ struct OrlgPhyParams {
     uint32_t *cs;           // [B][N*N*K][cs_len] channel_state lists (virtual layer), list order = array order
     uint8_t *cs_n;          // [B][N*N*K] list lengths
     OrlgPhyCand *cand;      // [B][cand_cap] defragmentation work list (only with defrag_period > 0)
+    uint32_t *ticket;       // work queue counter; environment = ticket - ticket_base
+    uint32_t ticket_base, pad_ticket;
     // shared tables
     const unsigned char *tables;   // blob staged into LDS
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
@@ -603,8 +605,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     }
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
-    const int env = blockIdx.x * (int)(blockDim.x >> 6) + wib;
-    if (env >= p.B) return;
     const PhyTab tb = make_phy_tab(smem, p);
     unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * p.l_wave_bytes;
     u64 *occ = reinterpret_cast<u64 *>(wb + p.l_occ);
@@ -616,6 +616,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     wv.lane = lane; wv.mt = mt;
 
     const int E = p.E, C = p.C, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
+    // work queue (as orlg_rmsa_kernel): a wave draws environments until the launch's B are taken
+    for (;;) {
+    uint32_t tk = 0;
+    if (lane == 0) {
+        const OrlgPhyParams __attribute__((address_space(4))) *kq =
+            (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+        tk = atomicAdd(kq->ticket, 1u) - p.ticket_base;
+    }
+    const int env = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    if ((uint32_t)env >= (uint32_t)p.B) break;
     OrlgPhySvc *grec = p.qrec + (size_t)env * Q;
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
@@ -1086,4 +1096,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             go->counted_defrag_cycles = ws->counted_defrag_cycles;
         }
     }
+    wave_sync();
+    }  // work queue
 }

@@ -16,6 +16,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=250)
     ap.add_argument("--load", type=float, default=1400)
     ap.add_argument("--metrics", action="store_true", help="also compute number_cuts_total / rss_total_metric every step")
+    ap.add_argument("--policy", default="bmfa", choices=["bmfa", "bmfa_rss", "sapff", "bmff", "sapbm", "faff", "faff_rss"])
+    ap.add_argument("--grooming", action="store_true")
+    ap.add_argument("--defrag", action="store_true", help="defrag_period=10, number_moves=10 (tests/test_rmsa_threads_us.py:190-251)")
+    ap.add_argument("--metric", default="cut")
+    ap.add_argument("--queue", type=int, default=0, help="queue_capacity (0 = from the load)")
     args = ap.parse_args()
     import torch
     from conftest import load_phy_tables, load_topology
@@ -23,14 +28,16 @@ def main():
     topo = load_topology("us14_3-paths_6-modulations")
     pairs, mod, gsnr = load_phy_tables("us14_k3")
     env = BatchedPhyRMSAEnv(topo, args.batch, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=args.load,
-                            mean_service_holding_time=25, episode_length=200, seed=10)
+                            mean_service_holding_time=25, episode_length=200, seed=10, grooming=args.grooming,
+                            defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None,
+                            metric=args.metric, queue_capacity=args.queue)
     outs = ("number_cuts_total", "rss_total_metric") if args.metrics else ()
 
     def run(k):
         left = k
         while left > 0:
             n = min(left, args.chunk)
-            env.run("bmfa", n, auto_reset=True, outputs=outs)
+            env.run(args.policy, n, auto_reset=True, outputs=outs)
             left -= n
     run(args.warmup)
     env.synchronize(); torch.cuda.synchronize()
@@ -39,7 +46,10 @@ def main():
     env.synchronize(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     red, _ = env.reduce_counters()
-    print(json.dumps({"metric": "env steps/s, PhyRMSA US14 bmfa(cut)", "value": args.batch * args.steps / dt,
+    st = env.episode_stats()
+    print(json.dumps({"metric": f"env steps/s, PhyRMSA US14 {args.policy}", "value": args.batch * args.steps / dt,
+                      "grooming": args.grooming, "defrag": args.defrag, "defrag_metric": args.metric,
+                      "queue_overflow": int(st["queue_overflow"].max()),
                       "batch": args.batch, "steps": args.steps, "load": args.load, "metrics_every_step": args.metrics,
                       "ms_per_step": dt * 1e3 / args.steps, "mean_running": float(env.num_running().mean()),
                       "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / red["services_processed"]}))

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where the step kernel's time goes: builds liborlg_sections.so (-DORLG_SECTIONS: s_memtime around every section of
+RMSAEnv.step, summed over all waves), runs the bench workload and prints the share of wave-cycles per section.
+usage (GPU box): python tools/section_profile.py [--stats full|network|counters] [--batch B]"""
+import argparse, ctypes as C, json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "optical-rl-gym-qot-aware_amd")
+LIB = os.path.join(PKG, "liborlg_sections.so")
+NAMES = ["idle/ticket", "state load", "policy", "validate+provision", "stats@provision", "queue insert", "outputs",
+         "next arrival", "refill", "release scan", "release apply", "stats@release", "done/reset", "state store", "", ""]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats", default="full")
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=1000)
+    args = ap.parse_args()
+    src = os.path.join(PKG, "csrc", "orlg_api.hip")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                    "-DORLG_SECTIONS", "-I", os.path.join(PKG, "csrc"), src, "-o", LIB], check=True)
+    os.environ["ORLG_LIB_PATH"] = LIB
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    from conftest import load_topology
+    from optical_rl_gym_amd import BatchedRMSAEnv, _lib
+    env = BatchedRMSAEnv(load_topology("nsfnet_chen_5-paths_6-modulations"), args.batch, num_spectrum_resources=320, load=50,
+                         mean_service_holding_time=25, episode_length=1000, seed=10, stats_level=args.stats)
+    env.run("sap_ff", 500, auto_reset=True)
+    L = _lib.load()
+    out = (C.c_ulonglong * 16)()
+    L.orlg_debug_sections(out, 1)
+    env.run("sap_ff", args.steps, auto_reset=True)
+    env.synchronize()
+    L.orlg_debug_sections(out, 1)
+    tot = sum(out)
+    res = {NAMES[i]: round(100.0 * out[i] / tot, 2) for i in range(14)}
+    res["cycles_per_env_step"] = tot / (args.batch * args.steps)
+    print(json.dumps({"stats": args.stats, "batch": args.batch, "percent_of_wave_cycles": res}))
+
+
+if __name__ == "__main__":
+    main()
