@@ -233,7 +233,8 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     auto up16 = [](int v) { return (v + 15) & ~15; };
     int off = 0;
     p.l_occ = off; off = up16(off + p.NW * 8);
-    p.l_qtime = off; off = up16(off + Q * 8);
+    p.l_nbt = off; off = up16(off + ORLG_PHY_NB * 8);
+    p.l_nbi = off; off = up16(off + ORLG_PHY_NB * 2);
     p.l_mt = off; off = up16(off + ORLG_MT_N * 4);
     p.l_scratch = off; off = up16(off + 256 + W * 64 * 8);
     p.l_wsc = off; off = up16(off + (int)sizeof(PhyWaveScalars));

@@ -9,9 +9,10 @@
 // _groom_defragmentation :703-733, _move_virtual :735-764 -- phy_defragmentation below.
 //
 // Same execution model as orlg_kernels.hip: one wavefront per environment, the link x channel free bitmap
-// (268 channels = 5 words per link), the release-time array and the MT19937 state live in LDS for the whole
-// launch; the 32-byte service records (path, channel list) stay in HBM and are touched only on provision /
-// release.  The QoT gate is the reference's: modulation_level[pair row][channel][k-path] (0 = unusable,
+// (268 channels = 5 words per link) and the MT19937 state live in LDS for the whole launch.  The release queue
+// (loads of 1400-4000 = that many running services) stays in HBM -- release times and 48-byte service records,
+// touched on provision / release -- and only the releases of the near future are kept in a small LDS buffer
+// (NearBuffer below): the per-wave LDS footprint decides how many environments a CU keeps resident.  The QoT gate is the reference's: modulation_level[pair row][channel][k-path] (0 = unusable,
 // capacity = level x 100 Gb/s) read from HBM in [row][k-path][channel] order (coalesced over channels).
 // Lanes are channels: lane l of word w owns channel 64w + l.
 #pragma once
@@ -19,6 +20,7 @@
 
 #define ORLG_PHY_MAX_CH 14
 #define ORLG_PHY_MAX_K 5
+#define ORLG_PHY_NB 128   // entries of the near-term release buffer (LDS)
 
 struct __attribute__((aligned(16))) OrlgPhySvc {  // one running service (HBM)
     double arrival;                // service.arrival_time (age of a defragmentation candidate)
@@ -88,7 +90,7 @@ struct OrlgPhyParams {
     const int16_t *act_channels;  // [B][ORLG_PHY_MAX_CH], -1 terminated; channel | used << 9 (used 0 = the full capacity)
     void *outs[ORLG_PHY_NUM_OUTS];
     // per-wave LDS layout
-    int32_t l_occ, l_qtime, l_mt, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
+    int32_t l_occ, l_nbt, l_nbi, l_mt, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
 };
 
 struct PhyWaveScalars {  // LDS
@@ -291,6 +293,49 @@ DEV bool cs_append(CsList &l, uint32_t v, int lane) {  // list.append
     return true;
 }
 
+
+// ---- near-term release buffer.  The release loop of _next_service (phy_rmsa_env.py:1009-1017) pops every event with
+// time <= now; with ~load running services a scan of all release times per step would need them all in LDS.  Instead
+// the LDS buffer holds (time, queue index) of every running service with release time <= horizon (it may hold a few
+// later ones too); now <= horizon always holds when the loop looks for due services, so the buffer is all it has to
+// read.  When the clock passes the horizon, or the buffer fills up, it is rebuilt from the HBM array with a horizon
+// that is expected to catch half a buffer (exponential holding times: n_running * holding_lambda releases per unit time).
+struct NearBuffer {
+    double *t;        // [ORLG_PHY_NB] release times
+    uint16_t *qi;     // [ORLG_PHY_NB] index of the service in the HBM queue
+    int n;
+    double horizon;
+};
+DEV int nb_collect(NearBuffer &nb, const double *gq, int n_running, double horizon, int lane) {
+    int cnt = 0;
+    for (int i0 = 0; i0 < n_running; i0 += 64) {
+        const int i = i0 + lane;
+        const double tq = i < n_running ? gq[i] : __longlong_as_double((long long)ORLG_INF_BITS);
+        const bool in = tq <= horizon;
+        const u64 m = ballot(in);
+        if (m) {
+            const int pos = cnt + popc64(m & ((1ull << lane) - 1ull));
+            if (in && pos < ORLG_PHY_NB) { nb.t[pos] = tq; nb.qi[pos] = (uint16_t)i; }
+            cnt += popc64(m);
+        }
+    }
+    wave_sync();
+    return cnt;
+}
+// returns false when even the services due right now do not fit (reported as a queue overflow)
+DEV bool nb_rebuild(NearBuffer &nb, const double *gq, int n_running, double now, double holding_lambda, int lane) {
+    double delta = (double)ORLG_PHY_NB / (2.0 * (double)(n_running > 0 ? n_running : 1) * holding_lambda);
+    for (int it = 0; it < 48; ++it) {
+        const double h = now + delta;
+        const int cnt = nb_collect(nb, gq, n_running, h, lane);
+        if (cnt <= ORLG_PHY_NB) { nb.n = cnt; nb.horizon = h; return true; }
+        delta *= 0.5;
+    }
+    const int cnt = nb_collect(nb, gq, n_running, now, lane);
+    nb.n = cnt <= ORLG_PHY_NB ? cnt : ORLG_PHY_NB;
+    nb.horizon = now;
+    return cnt <= ORLG_PHY_NB;
+}
 
 // channel_state list of a running service: (source, destination, k-path) key from its path record and direction flag
 DEV int svc_key(const PhyTab &tb, int N, int K, int gid, int flags) {
@@ -608,7 +653,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     const PhyTab tb = make_phy_tab(smem, p);
     unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * p.l_wave_bytes;
     u64 *occ = reinterpret_cast<u64 *>(wb + p.l_occ);
-    double *qtime = reinterpret_cast<double *>(wb + p.l_qtime);
+    NearBuffer nb;
+    nb.t = reinterpret_cast<double *>(wb + p.l_nbt);
+    nb.qi = reinterpret_cast<uint16_t *>(wb + p.l_nbi);
     uint32_t *mt = reinterpret_cast<uint32_t *>(wb + p.l_mt);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);  // selection lists + per-channel doubles
     PhyWaveScalars *ws = reinterpret_cast<PhyWaveScalars *>(wb + p.l_wsc);
@@ -627,6 +674,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     const int env = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
     if ((uint32_t)env >= (uint32_t)p.B) break;
     OrlgPhySvc *grec = p.qrec + (size_t)env * Q;
+    double *gq = p.qtime + (size_t)env * Q;   // release times, compact: entries 0..n_running-1 are live
+    nb.n = 0;
+    nb.horizon = -__longlong_as_double((long long)ORLG_INF_BITS);  // the first look at the queue rebuilds the buffer
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
 
@@ -636,8 +686,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     {
         const u64 *g = p.occ + (size_t)env * NW;
         for (int i = lane; i < NW; i += 64) occ[i] = g[i];
-        const double *gq = p.qtime + (size_t)env * Q;
-        for (int i = lane; i < n_running; i += 64) qtime[i] = gq[i];
         const uint32_t *gm = p.mt + (size_t)env * ORLG_MT_N;
         for (int i = lane; i < ORLG_MT_N; i += 64) mt[i] = gm[i];
         if (lane < 8) ws->c[lane] = gs->c[lane];
@@ -816,7 +864,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                     accepted = true;
                     if (n_running < Q) {
                         if (lane == 0) {
-                            qtime[n_running] = ws->req_arrival + ws->req_holding;
+                            gq[n_running] = ws->req_arrival + ws->req_holding;
                             OrlgPhySvc sv;
                             sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
                             sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(1 | (dirbit ? 2 : 0));
@@ -824,7 +872,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                                 sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) | (1 << 14)) : 0xffffu;
                             grec[n_running] = sv;
                         }
-                        n_running += 1;
+                        {   // _add_release: the release joins the near-term buffer when it falls before the horizon
+                            const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
+                            const int qidx = n_running;
+                            n_running += 1;
+                            if (rel <= nb.horizon) {
+                                if (nb.n < ORLG_PHY_NB) {
+                                    if (lane == 0) { nb.t[nb.n] = rel; nb.qi[nb.n] = (uint16_t)qidx; }
+                                    nb.n += 1;
+                                } else {
+                                    wave_sync();
+                                    if (!nb_rebuild(nb, gq, n_running, current_time, p.holding_lambda, lane) && lane == 0) ws->q_overflow |= 8;
+                                }
+                            }
+                        }
                         next_seq += 1;
                     } else if (lane == 0) {
                         ws->q_overflow |= 1;
@@ -886,7 +947,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                     // _add_release: compact queue, append at n_running
                     if (n_running < Q) {
                         if (lane == 0) {
-                            qtime[n_running] = ws->req_arrival + ws->req_holding;
+                            gq[n_running] = ws->req_arrival + ws->req_holding;
                             OrlgPhySvc sv;
                             sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
                             sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(dirbit ? 2 : 0);
@@ -896,7 +957,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
                                                       : 0xffffu;
                             grec[n_running] = sv;
                         }
-                        n_running += 1;
+                        {   // _add_release: the release joins the near-term buffer when it falls before the horizon
+                            const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
+                            const int qidx = n_running;
+                            n_running += 1;
+                            if (rel <= nb.horizon) {
+                                if (nb.n < ORLG_PHY_NB) {
+                                    if (lane == 0) { nb.t[nb.n] = rel; nb.qi[nb.n] = (uint16_t)qidx; }
+                                    nb.n += 1;
+                                } else {
+                                    wave_sync();
+                                    if (!nb_rebuild(nb, gq, n_running, current_time, p.holding_lambda, lane) && lane == 0) ws->q_overflow |= 8;
+                                }
+                            }
+                        }
                         next_seq += 1;
                     } else if (lane == 0) {
                         ws->q_overflow |= 1;
@@ -973,18 +1047,24 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             }
             // ---- release every service with release time <= now in time order (:1009-1017, _release_path :781-861):
             // with the virtual layer the order of simultaneous releases decides who frees a shared channel
+            wave_sync();
+            if (current_time > nb.horizon) {
+                if (!nb_rebuild(nb, gq, n_running, current_time, p.holding_lambda, lane) && lane == 0) ws->q_overflow |= 8;
+            }
             for (;;) {
                 double best_t = 0.0;
-                int victim = -1;
-                for (int q0 = 0; q0 < n_running; q0 += 64) {
-                    const int idx = q0 + lane;
-                    double tq = idx < n_running ? qtime[idx] : __longlong_as_double((long long)ORLG_INF_BITS);
+                int victim = -1, vpos = -1;
+                for (int c0 = 0; c0 < nb.n; c0 += 64) {
+                    const int c = c0 + lane;
+                    const double tq = c < nb.n ? nb.t[c] : __longlong_as_double((long long)ORLG_INF_BITS);
+                    const int qi = c < nb.n ? (int)nb.qi[c] : 0;
                     u64 m = ballot(tq <= current_time);
                     while (m) {
                         const int l = ctz64(m);
                         m &= m - 1;
                         const double tt = readlane_d(tq, l);
-                        if (victim < 0 || tt < best_t) { best_t = tt; victim = q0 + l; }
+                        const int qq = __builtin_amdgcn_readlane(qi, l);
+                        if (victim < 0 || tt < best_t || (tt == best_t && qq < victim)) { best_t = tt; victim = qq; vpos = c0 + l; }
                     }
                 }
                 if (victim < 0) break;
@@ -1033,12 +1113,22 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
 #pragma unroll
                     for (int w = 0; w < W; ++w) rowp[w] |= freemask[w];
                 }
-                // swap-remove: the last live entry takes the victim's place
+                // swap-remove: the last live entry takes the victim's place (its near-buffer entry follows it) ...
                 n_running -= 1;
-                if (victim != n_running && lane == 0) {
-                    qtime[victim] = qtime[n_running];
-                    grec[victim] = grec[n_running];
+                if (victim != n_running) {
+                    if (lane == 0) {
+                        gq[victim] = gq[n_running];
+                        grec[victim] = grec[n_running];
+                    }
+                    for (int c0 = 0; c0 < nb.n; c0 += 64) {
+                        const int c = c0 + lane;
+                        if (c < nb.n && (int)nb.qi[c] == n_running) nb.qi[c] = (uint16_t)victim;
+                    }
                 }
+                wave_sync();
+                // ... and the victim's own buffer entry is replaced by the buffer's last one
+                nb.n -= 1;
+                if (vpos != nb.n && lane == 0) { nb.t[vpos] = nb.t[nb.n]; nb.qi[vpos] = nb.qi[nb.n]; }
                 wave_sync();
             }
         }
@@ -1076,8 +1166,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
             (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         u64 *g = kp->occ + (size_t)env * NW;
         for (int i = lane; i < NW; i += 64) g[i] = occ[i];
-        double *gq = kp->qtime + (size_t)env * Q;
-        for (int i = lane; i < n_running; i += 64) gq[i] = qtime[i];
         uint32_t *gm = kp->mt + (size_t)env * ORLG_MT_N;
         for (int i = lane; i < ORLG_MT_N; i += 64) gm[i] = mt[i];
         OrlgPhyScalars *go = kp->scal + env;
