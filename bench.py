@@ -55,6 +55,27 @@ def cpu_baseline(topo, seconds=12.0):
             "sample": f"1 env x {done} steps, SAP-FF, same NSFNET-320 load-50 workload, oracle/orlg_oracle.c"}
 
 
+def north_star_measurement(topo, args, stream, dev):
+    """BASELINE.json north_star quotes its target (>= 10 M env-steps/s) at batch 65 536 on one MI355X: the same workload
+    and kernel at that batch, timed the same way (1 launch of warm-up, 2 timed launches), reported next to the headline."""
+    import torch
+    from optical_rl_gym_amd import BatchedRMSAEnv
+    B2 = 65536
+    env = BatchedRMSAEnv(topo, B2, **ENV_KW, seed=10, stats_level=args.stats, device=dev.index or 0)
+    env.set_stream(stream.cuda_stream)
+    env.run(args.policy, args.chunk, auto_reset=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        env.run(args.policy, args.chunk, auto_reset=True)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    red, _ = env.reduce_counters()
+    env.close()
+    return {"value": B2 * 2 * args.chunk / dt, "unit": "env steps/s", "batch": B2, "steps": 2 * args.chunk,
+            "ms_per_launch": dt * 1e3 / 2, "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / red["services_processed"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +86,7 @@ def main():
     ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
     ap.add_argument("--policy", default="sap_ff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the extra B=65536 measurement (north_star batch)")
     args = ap.parse_args()
 
     import numpy as np
@@ -176,6 +198,8 @@ def main():
                          "bit_rate_blocking_rate": float((stats[4] - stats[5]) / max(1, stats[4])),
                          "episodes_done": int(stats[8]), "num_envs": int(stats[9])},
         }
+        if world == 1 and not args.no_north_star and B != 65536:
+            out["north_star_batch_65536"] = north_star_measurement(topo, args, stream, dev)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(topo)
         print(json.dumps(out), flush=True)

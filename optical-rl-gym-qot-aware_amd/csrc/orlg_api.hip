@@ -41,6 +41,7 @@ struct orlg_env {
     size_t lds_block_bytes;
     int waves_per_block;
     int resident_blocks;   // workgroups of the step kernel the device keeps resident (grid size of the work queue)
+    int num_cu;
     uint32_t ticket_base;
     int num_paths;
     // owned device buffers
@@ -104,6 +105,7 @@ __global__ void orlg_clear_state_kernel(OrlgParams p, int W, int keep_rng) {
     }
     for (size_t i = tid; i < (size_t)p.B * 4 * p.NBR; i += nth) p.hist[i] = 0;
     for (size_t i = tid; i < (size_t)p.B * 4 * p.E; i += nth) p.lstat[i] = 0.0;
+    for (size_t i = tid; i < (size_t)p.B * p.lint_stride; i += nth) p.lint[i] = 0;
     for (size_t i = tid; i < (size_t)p.B; i += nth) {
         OrlgEnvScalars s;
         memset(&s, 0, sizeof(s));
@@ -170,22 +172,22 @@ __global__ void orlg_overflow_kernel(const OrlgEnvScalars *scal, int B, int *out
 // ---------------------------------------------------------------------------------------- kernel dispatch
 typedef void (*rmsa_kernel_t)(const OrlgParams);
 template <int W>
-static rmsa_kernel_t pick_stats(int stats) {
+static rmsa_kernel_t pick_stats(int stats, bool step) {
     switch (stats) {
-        case 0: return orlg_rmsa_kernel<W, 0>;
-        case 1: return orlg_rmsa_kernel<W, 1>;
-        default: return orlg_rmsa_kernel<W, 2>;
+        case 0: return step ? orlg_rmsa_kernel<W, 0> : orlg_rmsa_reset_kernel<W, 0>;
+        case 1: return step ? orlg_rmsa_kernel<W, 1> : orlg_rmsa_reset_kernel<W, 1>;
+        default: return step ? orlg_rmsa_kernel<W, 2> : orlg_rmsa_reset_kernel<W, 2>;
     }
 }
-static rmsa_kernel_t pick_rmsa(int W, int stats) {
+static rmsa_kernel_t pick_rmsa(int W, int stats, bool step = true) {
     switch (W) {
-        case 1: return pick_stats<1>(stats);
-        case 2: return pick_stats<2>(stats);
-        case 3: return pick_stats<3>(stats);
-        case 4: return pick_stats<4>(stats);
-        case 5: return pick_stats<5>(stats);
-        case 6: return pick_stats<6>(stats);
-        case 8: return pick_stats<8>(stats);
+        case 1: return pick_stats<1>(stats, step);
+        case 2: return pick_stats<2>(stats, step);
+        case 3: return pick_stats<3>(stats, step);
+        case 4: return pick_stats<4>(stats, step);
+        case 5: return pick_stats<5>(stats, step);
+        case 6: return pick_stats<6>(stats, step);
+        case 8: return pick_stats<8>(stats, step);
         default: return nullptr;
     }
 }
@@ -216,23 +218,24 @@ static masks_kernel_t pick_masks(int W) {
 }
 
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
-    rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level);
+    rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
     const int wpb = e->waves_per_block;
     if (e->resident_blocks <= 0) {
         int nb = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, e->device));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->lds_block_bytes));
-        e->resident_blocks = (nb > 0 ? nb : 1) * prop.multiProcessorCount;
+        rmsa_kernel_t ks = pick_rmsa(e->W, p.stats_level, true);  // the grid is sized for the step kernel (any grid is correct)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_block_bytes));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(ks), ORLG_WAVE * wpb, e->lds_block_bytes));
+        e->resident_blocks = (nb > 0 ? nb : 1) * e->num_cu;
     }
     int nblocks = (p.B + wpb - 1) / wpb;
     if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
     OrlgParams q = p;
     q.ticket_base = e->ticket_base;
-    e->ticket_base += (uint32_t)p.B + (uint32_t)(nblocks * wpb);  // every wave draws one ticket beyond its last environment
+    q.ticket_stride = (p.mode != ORLG_MODE_STEP || p.n_steps <= 16) ? 1u : 0u;
+    if (!q.ticket_stride) e->ticket_base += (uint32_t)p.B;  // waves * 1 static environment + (B - waves) tickets + one failing draw per wave
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
@@ -334,6 +337,11 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     memset(&e->p, 0, sizeof(e->p));
     e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
     e->resident_blocks = 0; e->ticket_base = 0;
+    {
+        hipDeviceProp_t prop;
+        hipError_t er = hipGetDeviceProperties(&prop, device);
+        e->num_cu = er == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     e->d_actions = nullptr; e->d_actions_cap = 0; e->num_paths = t->num_paths;
     for (int i = 0; i < 12; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -366,7 +374,8 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     p.l_mt = off; off = up16(off + ORLG_MT_N * 4);
     p.l_lstat = off; off = up16(off + 4 * E * 8);
     p.l_hist = off; off = up16(off + 4 * NBR * 4);
-    p.l_lint = off; off = up16(off + E * 4);
+    p.lint_stride = (E + 3) & ~3;
+    p.l_lint = off; off = up16(off + p.lint_stride * 4);
     p.l_scratch = off; off = up16(off + 64 * 16);
     p.l_wsc = off; off = up16(off + (int)sizeof(OrlgWaveScalars));
     p.l_ring = off; off = up16(off + ORLG_RING * (8 + 8 + 4));
@@ -447,6 +456,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     TRY(dev_alloc(e, &p.qdesc, (size_t)batch * Q));
     TRY(dev_alloc(e, &p.mt, (size_t)batch * ORLG_MT_N));
     TRY(dev_alloc(e, &p.scal, (size_t)batch));
+    TRY(dev_alloc(e, &p.lint, (size_t)batch * p.lint_stride));
     TRY(dev_alloc(e, &p.ticket, (size_t)4));
     {
         hipError_t er = hipMemset(p.ticket, 0, 16);
@@ -721,9 +731,12 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
     }
     rmsa_kernel_t k = pick_obs(e->W);
     const int wpb = e->waves_per_block;
-    size_t lds = (size_t)p.l_shared_bytes + (size_t)(((p.NW * 8 + 15) & ~15)) * wpb;
+    size_t lds = (size_t)p.l_shared_bytes + (size_t)(((p.NW * 8 + 15) & ~15) + ((p.obs_dim * 8 + 15) & ~15)) * wpb;
+    if (lds > 160 * 1024) return fail(ORLG_ERR_INVALID, "observation of %d values does not fit the LDS next to the tables", p.obs_dim);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((p.B + wpb - 1) / wpb), block(ORLG_WAVE * wpb);
+    int nblocks = (p.B + wpb - 1) / wpb;
+    if (nblocks > 4 * e->num_cu) nblocks = 4 * e->num_cu;   // a few workgroups per CU, each striding over its environments
+    dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds, e->stream, p);
     HIP_TRY(hipGetLastError());
     if (!dev) return copy_out(e, out, e->staging, bytes);

@@ -12,6 +12,7 @@
 #define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
 #define ORLG_NUM_OUTS 12
 #define ORLG_RING 64           // arrivals generated per refill (one per lane)
+#define ORLG_DIRECT_STEPS 4    // launches of at most this many steps read their ring entries straight from HBM
 
 // One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
 // "index" of every hop (utils.py:27-36, rmsa_env.py:479-483).
@@ -35,7 +36,8 @@ struct __attribute__((aligned(16))) OrlgEnvScalars {
     int32_t new_service;                                   // self._new_service
     int32_t q_overflow;                                    // release queue overflowed (error)
     int32_t ring_pos, ring_cnt;                            // pre-generated arrivals: next entry, entries left
-    int32_t pad[3];
+    int32_t sum_span, sum_gaps;                            // sums over the per-link (span, gaps) cache (_get_network_compactness)
+    int32_t pad;
 };
 static_assert(sizeof(OrlgEnvScalars) == 192, "OrlgEnvScalars layout");
 
@@ -74,6 +76,8 @@ struct OrlgParams {
     OrlgEnvScalars *scal;     // [B]
     int32_t *hist;            // [B][4][NBR] requested, provisioned, episode requested, episode provisioned
     double *lstat;            // [B][4][E] utilization, external_fragmentation, compactness, last_update
+    int32_t *lint;            // [B][lint_stride] per-link span | gaps << 16 (the cache behind _get_network_compactness)
+    int32_t lint_stride, pad_lint;
     double *ring_iat, *ring_ht;   // [B][64] pre-generated inter-arrival / holding times (in RNG stream order)
     uint32_t *ring_req;           // [B][64] src | dst << 8 | bit-rate index << 16
     // read-only tables: ONE blob in HBM that every workgroup stages into LDS (byte offsets t_*, 16-B aligned)
@@ -93,7 +97,8 @@ struct OrlgParams {
     // work queue: every wave draws environments from *ticket until the launch's B are taken (ticket - ticket_base
     // is the environment index; the host advances ticket_base by B + launched waves per launch, no memset needed)
     uint32_t *ticket;
-    uint32_t ticket_base, pad_ticket;
+    uint32_t ticket_base;
+    uint32_t ticket_stride;   // 1: static striding (env = wave, wave + waves, ...) instead of tickets: short launches
     // per-wave LDS layout (byte offsets from the wave's base) and size
     int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_ring, l_wave_bytes;
     int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions

@@ -144,6 +144,18 @@ DEV void stage_tables(unsigned char *smem, const OrlgParams &p) {
     __syncthreads();
 }
 
+// bulk copies between an environment's HBM arrays and the wave's LDS region: 16 bytes per lane per instruction (both sides
+// are 16-byte aligned: LDS offsets by construction, HBM per-env strides checked by the caller), 4-byte tail
+DEV void copy_words(void *dst, const void *src, int bytes, int lane) {
+    const int n16 = bytes >> 4;
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (int i = lane; i < n16; i += 64) d16[i] = s16[i];
+    const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
+    for (int i = (n16 << 2) + lane; i < (bytes >> 2); i += 64) d4[i] = s4[i];
+}
+
 // ---------------------------------------------------------------------------------------- MT19937
 // Regenerate all 624 words in place (CPython _randommodule.c genrand_uint32).  Sub-round r handles
 // kk = 64r + lane; mt[kk+1] is still old (same or later sub-round), mt[kk+397] is old for kk < 227 and
@@ -563,8 +575,10 @@ __device__ unsigned long long orlg_sections[16];
 #endif
 
 // ---------------------------------------------------------------------------------------- the step kernel
-template <int W, int STATS>
-__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
+// STEPK: the step kernel proper (mode STEP); the reset kernel (modes INIT / EPISODE_RESET: reset(), rmsa_env.py:343-457) is the
+// same body without the policy / provisioning part, under its own name so that kernel statistics keep the two apart.
+template <int W, int STATS, bool STEPK>
+DEV void rmsa_body(const OrlgParams &p) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
@@ -594,33 +608,101 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     // ------------------------------------------------------------------ work queue: one environment at a time per wave
     // (a wave that finishes early takes the next environment instead of idling until its workgroup drains; every
     // wave leaves through the same exit: the first ticket at or beyond B)
-    for (;;) {
-    uint32_t tk = 0;
-    if (lane == 0) tk = atomicAdd(kernarg_params()->ticket, 1u) - p.ticket_base;
-    const int env = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    if ((uint32_t)env >= (uint32_t)p.B) break;
-    SEC(1);  // state load
-    // ------------------------------------------------------------------ HBM -> LDS (coalesced)
-    {
-        const u64 *g = p.occ + (size_t)env * NW;
-        for (int i = lane; i < NW; i += 64) wv.occ[i] = g[i];
-        const double *gq = p.qtime + (size_t)env * Q;
-        const uint32_t *gd = p.qdesc + (size_t)env * Q;
-        for (int i = lane; i < Q; i += 64) { wv.qtime[i] = gq[i]; wv.qdesc[i] = gd[i]; }
-        const uint32_t *gm = p.mt + (size_t)env * ORLG_MT_N;
-        for (int i = lane; i < ORLG_MT_N; i += 64) wv.mt[i] = gm[i];
-        if (FULL) {
-            const double *gl = p.lstat + (size_t)env * 4 * E;
-            for (int i = lane; i < 4 * E; i += 64) wv.lst[i] = gl[i];
+    // The first environment of a wave is its own index (no atomic: all waves start at once); the remaining B - waves
+    // environments are handed out by the ticket counter.
+    const int n_static = (int)(gridDim.x * (blockDim.x >> 6)) < p.B ? (int)(gridDim.x * (blockDim.x >> 6)) : p.B;
+    int env = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+    if (env >= p.B) return;
+    // Long launches balance the load with the ticket counter (environments differ in work per step and a launch runs hundreds of
+    // steps); short ones -- the agent-driven pattern, a launch per step -- stride statically over the environments: tens of
+    // thousands of draws on one address would cost more than the steps themselves.  p.ticket_stride = 0 selects tickets.
+    uint32_t nxt_tk = 0;  // lane 0: the ticket drawn for this wave's next environment
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (bool first = true;; first = false) {
+    if (!first) {
+        if (p.ticket_stride) {
+            env += n_waves;
+            if (env >= p.B) break;
+        } else {
+            const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_tk) - p.ticket_base;
+            if (tk >= (uint32_t)(p.B - n_static)) break;
+            env = n_static + (int)tk;
         }
-        const int32_t *gh = p.hist + (size_t)env * 4 * NBR;
-        for (int i = lane; i < 4 * NBR; i += 64) wv.hist[i] = gh[i];
-        for (int i = lane; i < E; i += 64) wv.lint[i] = 0;
-        wv.ring_iat[lane] = p.ring_iat[(size_t)env * ORLG_RING + lane];
-        wv.ring_ht[lane] = p.ring_ht[(size_t)env * ORLG_RING + lane];
-        wv.ring_req[lane] = p.ring_req[(size_t)env * ORLG_RING + lane];
     }
-    const OrlgEnvScalars *gs = p.scal + env;
+    SEC(1);  // state load
+    // the next ticket is drawn now and looked at after this environment is done: its round trip is off the critical path
+    if (!p.ticket_stride && lane == 0) nxt_tk = atomicAdd(kernarg_params()->ticket, 1u);
+    // ------------------------------------------------------------------ HBM -> LDS (coalesced, 16 B per lane)
+    const int n_iter = STEPK ? p.n_steps : 1;
+    // The MT19937 state (2.5 KB) is only needed when the ring of pre-generated arrivals runs dry: it is fetched then.  A
+    // launch of a few steps (the agent-driven pattern: one launch per step) does not stage the ring either: it reads the
+    // entries it consumes straight from HBM -- the first one is requested as soon as the scalars are in -- and falls back to
+    // the LDS ring after a refill.
+    const bool direct_ring = n_iter <= ORLG_DIRECT_STEPS;
+    bool mt_loaded = false, ring_dirty = false, ring_in_lds = !direct_ring;
+    {
+        // the scalar record and every array's first 1 KiB block are requested before anything is written to LDS: one HBM
+        // round trip for the whole state, not one per array
+        const uint4 *g_sc = reinterpret_cast<const uint4 *>(p.scal + env);
+        const uint4 *g_occ = reinterpret_cast<const uint4 *>(p.occ + (size_t)env * NW);
+        const uint4 *g_qt = reinterpret_cast<const uint4 *>(p.qtime + (size_t)env * Q);
+        const uint4 *g_qd = reinterpret_cast<const uint4 *>(p.qdesc + (size_t)env * Q);
+        const uint4 *g_ls = reinterpret_cast<const uint4 *>(p.lstat + (size_t)env * 4 * E);
+        const uint4 *g_hi = reinterpret_cast<const uint4 *>(p.hist + (size_t)env * 4 * NBR);
+        const uint4 *g_li = reinterpret_cast<const uint4 *>(p.lint + (size_t)env * p.lint_stride);
+        const bool occ16 = (NW & 1) == 0;
+        const int n_occ = occ16 ? NW >> 1 : 0, n_qt = Q >> 1, n_qd = Q >> 2, n_ls = FULL ? 2 * E : 0, n_hi = NBR;
+        const int n_li = NET ? p.lint_stride >> 2 : 0;
+        constexpr int n_sc = (int)sizeof(OrlgEnvScalars) / 16;
+        uint4 a_sc = make_uint4(0, 0, 0, 0), a_occ = a_sc, a_qt = a_sc, a_qd = a_sc, a_ls = a_sc, a_hi = a_sc, a_li = a_sc;
+        if (lane < n_sc) a_sc = g_sc[lane];
+        if (lane < n_occ) a_occ = g_occ[lane];
+        if (lane < n_qt) a_qt = g_qt[lane];
+        if (lane < n_qd) a_qd = g_qd[lane];
+        if (lane < n_ls) a_ls = g_ls[lane];
+        if (lane < n_hi) a_hi = g_hi[lane];
+        if (lane < n_li) a_li = g_li[lane];
+        if (lane < n_sc) reinterpret_cast<uint4 *>(wv.scratch)[lane] = a_sc;
+        if (lane < n_occ) reinterpret_cast<uint4 *>(wv.occ)[lane] = a_occ;
+        if (lane < n_qt) reinterpret_cast<uint4 *>(wv.qtime)[lane] = a_qt;
+        if (lane < n_qd) reinterpret_cast<uint4 *>(wv.qdesc)[lane] = a_qd;
+        if (lane < n_ls) reinterpret_cast<uint4 *>(wv.lst)[lane] = a_ls;
+        if (lane < n_hi) reinterpret_cast<uint4 *>(wv.hist)[lane] = a_hi;
+        if (lane < n_li) reinterpret_cast<uint4 *>(wv.lint)[lane] = a_li;
+        for (int i = lane + 64; i < n_li; i += 64) reinterpret_cast<uint4 *>(wv.lint)[i] = g_li[i];
+        for (int i = lane + 64; i < n_occ; i += 64) reinterpret_cast<uint4 *>(wv.occ)[i] = g_occ[i];
+        for (int i = lane + 64; i < n_qt; i += 64) reinterpret_cast<uint4 *>(wv.qtime)[i] = g_qt[i];
+        for (int i = lane + 64; i < n_qd; i += 64) reinterpret_cast<uint4 *>(wv.qdesc)[i] = g_qd[i];
+        for (int i = lane + 64; i < n_ls; i += 64) reinterpret_cast<uint4 *>(wv.lst)[i] = g_ls[i];
+        for (int i = lane + 64; i < n_hi; i += 64) reinterpret_cast<uint4 *>(wv.hist)[i] = g_hi[i];
+        if (!occ16) {
+            const u64 *g = p.occ + (size_t)env * NW;
+            for (int i = lane; i < NW; i += 64) wv.occ[i] = g[i];
+        }
+        if (!direct_ring) {
+            wv.ring_iat[lane] = p.ring_iat[(size_t)env * ORLG_RING + lane];
+            wv.ring_ht[lane] = p.ring_ht[(size_t)env * ORLG_RING + lane];
+            wv.ring_req[lane] = p.ring_req[(size_t)env * ORLG_RING + lane];
+        }
+    }
+    wave_sync();
+    // wave-uniform working copies (the scalar record sits in the scratch area until the first statistics pass reuses it)
+    const OrlgEnvScalars *gs = reinterpret_cast<const OrlgEnvScalars *>(wv.scratch);
+    int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
+    double pf_iat = 0.0, pf_ht = 0.0;   // direct mode: the ring entry of the launch's first arrival, requested early
+    uint32_t pf_rq = 0;
+    if (direct_ring && ring_cnt > 0) {
+        KernargParams kq = kernarg_params();
+        const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+        pf_iat = kq->ring_iat[ro]; pf_ht = kq->ring_ht[ro]; pf_rq = kq->ring_req[ro];
+    }
+    double current_time = gs->current_time;
+    double comp_cur = 1.0;  // _get_network_compactness() of the current occupancy
+    int sum_sh = gs->sum_slots_hops;
+    const int gs_sum_span = gs->sum_span, gs_sum_gaps = gs->sum_gaps;
+    int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
+    int mt_idx = gs->mt_idx, new_service = gs->new_service;
+    int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
     if (lane == 0) {
         wv.wsc->sum_bitrate_running = gs->sum_bitrate_running;
@@ -630,27 +712,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
         wv.wsc->g_thr = gs->g_throughput; wv.wsc->g_comp = gs->g_compactness; wv.wsc->g_lu = gs->g_last_update;
         wv.wsc->req_arrival = gs->req_arrival; wv.wsc->req_holding = gs->req_holding;
     }
-    // wave-uniform working copies
-    double current_time = gs->current_time;
-    double comp_cur = 1.0;  // _get_network_compactness() of the current occupancy
-    int sum_sh = gs->sum_slots_hops;
-    int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
-    int mt_idx = gs->mt_idx, new_service = gs->new_service;
-    int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
-    int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     wave_sync();
 
+    // the per-link (span, gaps) cache and its sums travel with the state (they are a function of the occupancy)
+    int sum_span = gs_sum_span, sum_gaps = gs_sum_gaps;
+    if (NET) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
 
-    int sum_span = 0, sum_gaps = 0;
-    if (NET) {
-        link_stats_update<W, false, false>(wv, tb, S, E, nullptr, E, 0.0, sum_span, sum_gaps, comp_cur, sum_sh, 0.0);
-        comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
-    }
-
-    const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy
-        if (p.mode == ORLG_MODE_STEP) {
+        if (STEPK) {
             // ========================================================== policy: pick (path, slot)
             const int base = tb.pair_base[req_src * N + req_dst];
             // (path, word) lanes: AND over the links of candidate path pp
@@ -822,17 +892,34 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
 
         // ============================================================== _next_service (rmsa_env.py:643-695)
         SEC(7);  // next arrival
-        if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
+        if ((STEPK || p.mode != ORLG_MODE_EPISODE_RESET) && !new_service) {
             if (ring_cnt == 0) {
                 SEC(8);  // refill
+                if (!mt_loaded) {
+                    copy_words(wv.mt, kernarg_params()->mt + (size_t)env * ORLG_MT_N, ORLG_MT_N * 4, lane);
+                    mt_loaded = true;
+                    wave_sync();
+                }
+                ring_dirty = true;
+                ring_in_lds = true;
                 ring_cnt = refill_requests(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
                                            &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda);
                 ring_pos = 0;
                 SEC(7);
             }
-            const double at = current_time + wv.ring_iat[ring_pos];
-            const double ht = wv.ring_ht[ring_pos];
-            const uint32_t rq = wv.ring_req[ring_pos];
+            double r_iat, r_ht;
+            uint32_t rq;
+            if (ring_in_lds) {
+                r_iat = wv.ring_iat[ring_pos]; r_ht = wv.ring_ht[ring_pos]; rq = wv.ring_req[ring_pos];
+            } else if (t == 0) {
+                r_iat = pf_iat; r_ht = pf_ht; rq = pf_rq;
+            } else {
+                KernargParams kq = kernarg_params();
+                const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+                r_iat = kq->ring_iat[ro]; r_ht = kq->ring_ht[ro]; rq = kq->ring_req[ro];
+            }
+            const double at = current_time + r_iat;
+            const double ht = r_ht;
             ring_pos += 1; ring_cnt -= 1;
             current_time = at;
             const int src = (int)(rq & 0xffu), dst = (int)((rq >> 8) & 0xffu), bri = (int)(rq >> 16);
@@ -890,7 +977,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
         }
 
         SEC(12);  // done / episode reset
-        if (p.mode == ORLG_MODE_STEP) {
+        if (STEPK) {
             const bool done = (eproc == p.episode_length);
             if (lane == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
                 reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
@@ -915,23 +1002,25 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
     wave_sync();
     {
         KernargParams kp = kernarg_params();
-        u64 *g = kp->occ + (size_t)env * NW;
-        for (int i = lane; i < NW; i += 64) g[i] = wv.occ[i];
-        double *gq = kp->qtime + (size_t)env * Q;
-        uint32_t *gd = kp->qdesc + (size_t)env * Q;
-        for (int i = lane; i < Q; i += 64) { gq[i] = wv.qtime[i]; gd[i] = wv.qdesc[i]; }
-        uint32_t *gm = kp->mt + (size_t)env * ORLG_MT_N;
-        for (int i = lane; i < ORLG_MT_N; i += 64) gm[i] = wv.mt[i];
-        if (FULL) {
-            double *gl = kp->lstat + (size_t)env * 4 * E;
-            for (int i = lane; i < 4 * E; i += 64) gl[i] = wv.lst[i];
+        if ((NW & 1) == 0) {
+            copy_words(kp->occ + (size_t)env * NW, wv.occ, NW * 8, lane);
+        } else {
+            u64 *g = kp->occ + (size_t)env * NW;
+            for (int i = lane; i < NW; i += 64) g[i] = wv.occ[i];
         }
-        int32_t *gh = kp->hist + (size_t)env * 4 * NBR;
-        for (int i = lane; i < 4 * NBR; i += 64) gh[i] = wv.hist[i];
-        kp->ring_iat[(size_t)env * ORLG_RING + lane] = wv.ring_iat[lane];
-        kp->ring_ht[(size_t)env * ORLG_RING + lane] = wv.ring_ht[lane];
-        kp->ring_req[(size_t)env * ORLG_RING + lane] = wv.ring_req[lane];
-        OrlgEnvScalars *go = kp->scal + env;
+        copy_words(kp->qtime + (size_t)env * Q, wv.qtime, Q * 8, lane);
+        copy_words(kp->qdesc + (size_t)env * Q, wv.qdesc, Q * 4, lane);
+        if (mt_loaded) copy_words(kp->mt + (size_t)env * ORLG_MT_N, wv.mt, ORLG_MT_N * 4, lane);
+        if (FULL) copy_words(kp->lstat + (size_t)env * 4 * E, wv.lst, 4 * E * 8, lane);
+        copy_words(kp->hist + (size_t)env * 4 * NBR, wv.hist, 4 * NBR * 4, lane);
+        if (NET) copy_words(kp->lint + (size_t)env * kp->lint_stride, wv.lint, kp->lint_stride * 4, lane);
+        if (ring_dirty) {
+            kp->ring_iat[(size_t)env * ORLG_RING + lane] = wv.ring_iat[lane];
+            kp->ring_ht[(size_t)env * ORLG_RING + lane] = wv.ring_ht[lane];
+            kp->ring_req[(size_t)env * ORLG_RING + lane] = wv.ring_req[lane];
+        }
+        // the scalar record is assembled in the scratch area and leaves as one 192-byte row
+        OrlgEnvScalars *go = reinterpret_cast<OrlgEnvScalars *>(wv.scratch);
         const OrlgWaveScalars *ws = wv.wsc;
         if (lane < 8) go->c[lane] = ws->c[lane];
         if (lane == 0) {
@@ -944,12 +1033,25 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_r
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
+            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
         }
+        wave_sync();
+        if (lane < (int)sizeof(OrlgEnvScalars) / 16)
+            reinterpret_cast<uint4 *>(kp->scal + env)[lane] = reinterpret_cast<const uint4 *>(wv.scratch)[lane];
     }
     wave_sync();
     SEC(0);
     }  // work queue
     SEC_FLUSH;
+}
+
+template <int W, int STATS>
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
+    rmsa_body<W, STATS, true>(p);
+}
+template <int W, int STATS>
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_reset_kernel(const OrlgParams p) {
+    rmsa_body<W, STATS, false>(p);
 }
 
 // ---------------------------------------------------------------------------------------- queries
@@ -978,7 +1080,9 @@ __global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgPa
     if (lane < cnt) nslots[lane] = tb.nslots[sc->req_br * ORLG_NSLOT_STRIDE + tb.recs[base + lane].se];
 }
 
-// DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env; one wave per env.
+// DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env.  One wave per env at a time: the grid is sized to the
+// device and strides over the environments (the topology tables are staged once per workgroup); the vector is put
+// together in LDS and leaves as one coalesced row of obs_dim doubles.
 template <int W>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deeprmsa_obs_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -986,55 +1090,62 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
     const Tab tb = make_tab(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
-    const int env = blockIdx.x * (int)(blockDim.x >> 6) + wib;
-    if (env >= p.B) return;
-    u64 *occ = reinterpret_cast<u64 *>(smem + p.l_shared_bytes + (size_t)wib * ((p.NW * 8 + 15) & ~15));
-    const u64 *g = p.occ + (size_t)env * p.NW;
-    for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
-    wave_sync();
-    const OrlgEnvScalars *sc = p.scal + env;
+    const int occ_bytes = (p.NW * 8 + 15) & ~15, obs_bytes = (p.obs_dim * 8 + 15) & ~15;
+    unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * (occ_bytes + obs_bytes);
+    u64 *occ = reinterpret_cast<u64 *>(wb);
+    double *out = reinterpret_cast<double *>(wb + occ_bytes);
     const int N = p.N, K = p.K, S = p.S, J = p.j;
-    const int src = sc->req_src, dst = sc->req_dst, br = sc->req_br;
-    double *out = p.o_obs + (size_t)env * p.obs_dim;
-    const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
-    // bit rate + one-hot endpoints
-    if (lane == 0) out[0] = (double)tb.bit_rates[br] / 100;
-    for (int i = lane; i < 2 * N; i += 64) out[1 + i] = (i == mn || i == N + mx) ? 1.0 : 0.0;
-    const int base = tb.pair_base[src * N + dst];
-    const int pp = lane / W, pw = lane - pp * W;
-    u64 acc = 0ull;
-    acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-    int my_se = 0;
-    if (lane < K) my_se = tb.recs[base + lane].se;
-    int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
-    const int PW = 2 * J + 3;
-    double *sp = out + 1 + 2 * N;
-    for (int idp = 0; idp < K; ++idp) {
-        u64 x[W];
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int env = blockIdx.x * (int)(blockDim.x >> 6) + wib; env < p.B; env += n_waves) {
+        const u64 *g = p.occ + (size_t)env * p.NW;
+        const OrlgEnvScalars *sc = p.scal + env;
+        const int src = sc->req_src, dst = sc->req_dst, br = sc->req_br;
+        for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
+        wave_sync();
+        const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
+        // bit rate + one-hot endpoints
+        if (lane == 0) out[0] = (double)tb.bit_rates[br] / 100;
+        for (int i = lane; i < 2 * N; i += 64) out[1 + i] = (i == mn || i == N + mx) ? 1.0 : 0.0;
+        const int base = tb.pair_base[src * N + dst];
+        const int pp = lane / W, pw = lane - pp * W;
+        u64 acc = 0ull;
+        acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
+        int my_se = 0;
+        if (lane < K) my_se = tb.recs[base + lane].se;
+        int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
+        const int PW = 2 * J + 3;
+        double *sp = out + 1 + 2 * N;
+        for (int idp = 0; idp < K; ++idp) {
+            u64 x[W];
 #pragma unroll
-        for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
-        const int n = __builtin_amdgcn_readlane(my_n, idp);
-        double *row = sp + idp * PW;
-        for (int b = 0; b < J; ++b) {
-            int len = 0;
-            int s0 = find_block<W>(x, n, b, lane, &len);
+            for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
+            const int n = __builtin_amdgcn_readlane(my_n, idp);
+            double *row = sp + idp * PW;
+            for (int b = 0; b < J; ++b) {
+                int len = 0;
+                int s0 = find_block<W>(x, n, b, lane, &len);
+                if (lane == 0) {
+                    row[2 * b] = s0 >= 0 ? 2 * ((double)s0 - 0.5 * S) / S : -1.0;
+                    row[2 * b + 1] = s0 >= 0 ? ((double)len - 8) / 8 : -1.0;
+                }
+            }
+            int total = 0, runs = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                u64 carry = w > 0 ? (x[w > 0 ? w - 1 : 0] >> 63) : 0ull;
+                total += popc64(x[w]);
+                runs += popc64(x[w] & ~((x[w] << 1) | carry));
+            }
             if (lane == 0) {
-                row[2 * b] = s0 >= 0 ? 2 * ((double)s0 - 0.5 * S) / S : -1.0;
-                row[2 * b + 1] = s0 >= 0 ? ((double)len - 8) / 8 : -1.0;
+                row[2 * J] = ((double)n - 5.5) / 3.5;
+                row[2 * J + 1] = 2 * ((double)total - 0.5 * S) / S;
+                row[2 * J + 2] = runs > 0 ? ((double)total / (double)runs - 4) / 4 : -1.0;
             }
         }
-        int total = 0, runs = 0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            u64 carry = w > 0 ? (x[w > 0 ? w - 1 : 0] >> 63) : 0ull;
-            total += popc64(x[w]);
-            runs += popc64(x[w] & ~((x[w] << 1) | carry));
-        }
-        if (lane == 0) {
-            row[2 * J] = ((double)n - 5.5) / 3.5;
-            row[2 * J + 1] = 2 * ((double)total - 0.5 * S) / S;
-            row[2 * J + 2] = runs > 0 ? ((double)total / (double)runs - 4) / 4 : -1.0;
-        }
+        wave_sync();
+        double *gout = p.o_obs + (size_t)env * p.obs_dim;
+        for (int i = lane; i < p.obs_dim; i += 64) gout[i] = out[i];
+        wave_sync();
     }
 }
 

@@ -114,7 +114,8 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
     OrlgPhyParams q = p;
     q.ticket_base = e->ticket_base;
-    e->ticket_base += (uint32_t)p.B + (uint32_t)(nblocks * wpb);
+    q.ticket_stride = (p.mode != ORLG_MODE_STEP || p.n_steps <= 16) ? 1u : 0u;
+    if (!q.ticket_stride) e->ticket_base += (uint32_t)p.B;
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());

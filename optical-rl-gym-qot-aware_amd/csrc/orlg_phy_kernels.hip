@@ -78,7 +78,7 @@ struct OrlgPhyParams {
     uint8_t *cs_n;          // [B][N*N*K] list lengths
     OrlgPhyCand *cand;      // [B][cand_cap] defragmentation work list (only with defrag_period > 0)
     uint32_t *ticket;       // work queue counter; environment = ticket - ticket_base
-    uint32_t ticket_base, pad_ticket;
+    uint32_t ticket_base, ticket_stride;
     // shared tables
     const unsigned char *tables;   // blob staged into LDS
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
@@ -663,16 +663,29 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_p
     wv.lane = lane; wv.mt = mt;
 
     const int E = p.E, C = p.C, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
-    // work queue (as orlg_rmsa_kernel): a wave draws environments until the launch's B are taken
-    for (;;) {
-    uint32_t tk = 0;
-    if (lane == 0) {
+    // work queue (as orlg_rmsa_kernel): long launches draw environments from the ticket counter (the next ticket is drawn
+    // while the current environment runs), short ones stride statically
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int n_static = n_waves < p.B ? n_waves : p.B;
+    int env = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+    if (env >= p.B) return;
+    uint32_t nxt_tk = 0;
+    for (bool first = true;; first = false) {
+    if (!first) {
+        if (p.ticket_stride) {
+            env += n_waves;
+            if (env >= p.B) break;
+        } else {
+            const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_tk) - p.ticket_base;
+            if (tk >= (uint32_t)(p.B - n_static)) break;
+            env = n_static + (int)tk;
+        }
+    }
+    if (!p.ticket_stride && lane == 0) {
         const OrlgPhyParams __attribute__((address_space(4))) *kq =
             (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-        tk = atomicAdd(kq->ticket, 1u) - p.ticket_base;
+        nxt_tk = atomicAdd(kq->ticket, 1u);
     }
-    const int env = (int)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-    if ((uint32_t)env >= (uint32_t)p.B) break;
     OrlgPhySvc *grec = p.qrec + (size_t)env * Q;
     double *gq = p.qtime + (size_t)env * Q;   // release times, compact: entries 0..n_running-1 are live
     nb.n = 0;

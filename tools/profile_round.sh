@@ -7,7 +7,7 @@ tag=$1; shift
 out=gpurun_out/profile_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-ARGS="--no-cpu-baseline $@"
+ARGS="--no-cpu-baseline --no-north-star $@"
 python bench.py $ARGS > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python bench.py $ARGS > $out/kt.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/pmc_inst -- python bench.py $ARGS > $out/pmc_inst.log 2>&1
@@ -22,7 +22,7 @@ for f in glob.glob(out + "/kt/*/*kernel_stats.csv"):
     summary["kernel_stats"] = [r for r in csv.DictReader(open(f))]
 step = [r for r in csv.DictReader(open(glob.glob(out + "/kt/*/*kernel_trace.csv")[0])) if "orlg_rmsa_kernel" in r["Kernel_Name"]]
 durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
-full = [d for d in durs if d > 0.5 * durs[-1]]
+full = [d for d in durs if d > 0.75 * durs[-1]]
 summary["step_kernel"] = {"name": step[0]["Kernel_Name"], "launches": len(durs), "full_launches": len(full),
                           "avg_ns_full_launch": sum(full) / len(full), "vgpr": step[-1]["VGPR_Count"], "sgpr": step[-1]["SGPR_Count"],
                           "scratch": step[-1]["Scratch_Size"], "workgroup": step[-1]["Workgroup_Size_X"], "grid": step[-1]["Grid_Size_X"]}
@@ -35,7 +35,7 @@ for d in ("pmc_inst", "pmc_busy", "pmc_fetch", "pmc_write"):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             v = sorted(v)
-            big = [x for x in v if x > 0.5 * v[-1]] or v
+            big = [x for x in v if x > 0.75 * v[-1]] or v
             pmc[k] = sum(big) / len(big)
 summary["pmc_per_full_launch"] = pmc
 b = summary["bench"]

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "optical-rl-gym-qot-aware_amd")
 LIB = os.path.join(PKG, "liborlg_sections.so")
 NAMES = ["idle/ticket", "state load", "policy", "validate+provision", "stats@provision", "queue insert", "outputs",
-         "next arrival", "refill", "release scan", "release apply", "stats@release", "done/reset", "state store", "", ""]
+         "next arrival", "refill", "release scan", "release apply", "stats@release", "done/reset", "state store", "link cache init", ""]
 
 
 def main():
@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--stats", default="full")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--chunk", type=int, default=0, help="env steps per launch (0 = all in one launch)")
     args = ap.parse_args()
     src = os.path.join(PKG, "csrc", "orlg_api.hip")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -30,11 +31,13 @@ def main():
     L = _lib.load()
     out = (C.c_ulonglong * 16)()
     L.orlg_debug_sections(out, 1)
-    env.run("sap_ff", args.steps, auto_reset=True)
+    chunk = args.chunk or args.steps
+    for _ in range(args.steps // chunk):
+        env.run("sap_ff", chunk, auto_reset=True)
     env.synchronize()
     L.orlg_debug_sections(out, 1)
     tot = sum(out)
-    res = {NAMES[i]: round(100.0 * out[i] / tot, 2) for i in range(14)}
+    res = {NAMES[i]: round(100.0 * out[i] / tot, 2) for i in range(15)}
     res["cycles_per_env_step"] = tot / (args.batch * args.steps)
     print(json.dumps({"stats": args.stats, "batch": args.batch, "percent_of_wave_cycles": res}))
 
