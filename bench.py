@@ -80,7 +80,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--chunk", type=int, default=1000, help="env steps per kernel launch")
     ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
