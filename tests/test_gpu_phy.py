@@ -189,3 +189,30 @@ def test_phy_batch_4096_properties():
     red, _ = env.reduce_counters()
     assert red["num_envs"] == 4096 and red["services_processed"] == 4096 * 301
     env.close()
+
+
+def test_phy_work_queue_more_envs_than_resident_waves(device_log_in_oracle):
+    """B = 9000 > resident waves: ticket mode for the long launches, static striding for the short ones; the near-term
+    release buffer is rebuilt at every launch.  Sampled environments bit-exact against the oracle."""
+    z, meta = load_golden("phy_us14_s10_sapff")
+    topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
+    kw = dict(meta["env_kwargs"], seed=500, load=600)
+    B = 9000
+    env = make_env(topo, tables, kw, B)
+    env.run("sapff", 80, auto_reset=True)
+    for _ in range(3):
+        env.run("sapff", 4, auto_reset=True)
+    tr = env.run("sapff", 60, outputs=("act_path", "channels", "accepted"), auto_reset=True)
+    cnt, av = env.counters(), env.available_channels()
+    assert env.episode_stats()["queue_overflow"].max() == 0
+    for i in (0, 4095, 4096, 8191, 8192, 8999):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=500 + i)
+        o.run("sapff", 92, reset_on_done=True, fields=[])
+        ot = o.run("sapff", 60, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(av[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        assert env.channel_state(i) == o.channel_state(), i
+        o.close()
+    env.close()

@@ -226,6 +226,31 @@ def test_batch_4096_properties(nsfnet, device_log_in_oracle):
     env.close()
 
 
+def test_work_queue_more_envs_than_resident_waves(nsfnet, device_log_in_oracle):
+    """B = 20 000 > the 4096 waves a MI355X keeps resident: the long launch hands environments out through the ticket
+    counter (several launches: the host-side ticket base must advance correctly), the short ones stride statically.
+    Sampled environments, incl. the first and last of every kind, are bit-exact against the oracle."""
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=77)
+    B = 20000
+    env = make_batched(nsfnet, kw, B)
+    env.run("sap_ff", 120)                                   # ticket mode
+    for _ in range(3):
+        env.run("sap_ff", 5)                                 # static striding
+    tr = env.run("sap_ff", 100, outputs=("act_path", "act_slot", "accepted"))   # ticket mode again, with outputs
+    cnt = env.counters()
+    assert np.all(cnt["services_processed"] == 236)
+    occ, now = env.available_slots(), env.current_time()
+    for i in (0, 4095, 4096, 4097, 8191, 8192, 12345, 19999):
+        o = oracle_env_from_kwargs(nsfnet, kw, seed=77 + i)
+        o.run("sap_ff", 135, fields=[])
+        ot = o.run("sap_ff", 100)
+        assert np.array_equal(tr["act_slot"][:, i], ot["act_slot"]) and np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(occ[i], o.available_slots()) and now[i] == o.current_time(), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        o.close()
+    env.close()
+
+
 def test_full_reset_keeps_rng_stream(nsfnet, device_log_in_oracle):
     kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=5)
     env = make_batched(nsfnet, kw, 3)
