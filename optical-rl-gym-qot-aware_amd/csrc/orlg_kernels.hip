@@ -418,20 +418,39 @@ DEV KernargParams kernarg_params() {
 // for links with more than one used run, 0 otherwise.  links == nullptr means links 0..nlinks-1.
 // GRAPH: after the last chunk also perform _update_network_stats (rmsa_env.py:537-560) -- its two
 // time-weighted averages ride on lanes 62 / 63 of the same fp64 instruction stream as the links'.
+// reductions over the 8 lanes of a link group (lane = link slot * 8 + word) with DPP lane permutations: xor 1 and xor 2
+// inside a quad, then the mirrored half row brings in the other quad's total -- every lane ends with the group's result
+DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
+DEV int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }   // quad_perm [2,3,0,1]
+DEV int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); }
+DEV int group8_add(int v) { v += dpp_xor1(v); v += dpp_xor2(v); v += dpp_half_mirror(v); return v; }
+DEV int group8_min(int v) {
+    int o = dpp_xor1(v); v = o < v ? o : v;
+    o = dpp_xor2(v); v = o < v ? o : v;
+    o = dpp_half_mirror(v); return o < v ? o : v;
+}
+DEV int group8_max(int v) {
+    int o = dpp_xor1(v); v = o > v ? o : v;
+    o = dpp_xor2(v); v = o > v ? o : v;
+    o = dpp_half_mirror(v); return o > v ? o : v;
+}
+
 template <int W, bool LINKF, bool GRAPH>
 DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
                            int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr) {
-    constexpr int HPC = 64 / W;  // links per chunk
+    static_assert(W <= 8, "a link group is 8 lanes");
+    constexpr int HPC = 8;  // links per chunk: lane = link slot * 8 + word
     const int lane = wv.lane;
-    const int hl = lane / W, w = lane - hl * W;
+    const int hl = lane >> 3, w = lane & 7;
     double ynow = 0.0;
     if ((LINKF || GRAPH) && now > 0) ynow = recip_refine(now);
     for (int h0 = 0; h0 < nlinks; h0 += HPC) {
         const int nl = nlinks - h0 < HPC ? nlinks - h0 : HPC;
         const bool last_chunk = h0 + HPC >= nlinks;
-        // ---- phase A: (link, word) lanes
-        if (hl < nl) {
-            int link = links ? (int)links[h0 + hl] : h0 + hl;
+        // ---- per (link, word) lane: the word's run statistics ...
+        int link = 0, packed = 0, lo = 0x7fff, hi = 0, ml = 0;
+        if (hl < nl) link = links ? (int)links[h0 + hl] : h0 + hl;
+        if (hl < nl && w < W) {
             const u64 *row = wv.occ + __mul24(link, W);
             u64 x = row[w];
             u64 prev = w > 0 ? row[w - 1] : 0ull;
@@ -440,10 +459,9 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
             u64 carry_u = w > 0 ? ((~prev) >> 63) : 0ull;
             u64 fstarts = x & ~((x << 1) | carry_f);
             u64 ustarts = u & ~((u << 1) | carry_u);
-            int pf = popc64(x), nfs = popc64(fstarts), nus = popc64(ustarts);
-            int lo = u ? 64 * w + ctz64(u) : 0x7fff;
-            int hi = u ? 64 * w + 64 - clz64(u) : 0;
-            int ml = 0;
+            packed = popc64(x) | (popc64(fstarts) << 10) | (popc64(ustarts) << 20);  // free slots, free runs, used runs
+            lo = u ? 64 * w + ctz64(u) : 0x7fff;
+            hi = u ? 64 * w + 64 - clz64(u) : 0;
             if (LINKF) {
                 int e = 0;
                 if ((x >> 63) && w < W - 1) {
@@ -461,30 +479,15 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                     ml = len > ml ? len : ml;
                 }
             }
-            uint32_t *sc = wv.scratch + lane * 4;
-            sc[0] = (uint32_t)pf | ((uint32_t)nfs << 16);
-            sc[1] = (uint32_t)nus | ((uint32_t)ml << 16);
-            sc[2] = (uint32_t)lo | ((uint32_t)hi << 16);
         }
-        wave_sync();
-        // ---- phase B (integers): one lane per link
+        // ---- ... combined over the link's words inside its 8-lane group (no LDS round trip)
+        packed = group8_add(packed);
+        const int lmin = group8_min(lo), lmax = group8_max(hi);
+        if (LINKF) ml = group8_max(ml);
+        const int freec = packed & 0x3ff, F = (packed >> 10) & 0x3ff, U = packed >> 20;
+        const bool link_lane = hl < nl && w == 0;  // one lane per link carries on
         int dspan = 0, dgaps = 0;
-        int link = 0, freec = 0, F = 0, U = 0, ml = 0, lmin = 0x7fff, lmax = 0;
-        if (lane < nl) {
-            link = links ? (int)links[h0 + lane] : h0 + lane;
-#pragma unroll
-            for (int q = 0; q < W; ++q) {
-                const uint32_t *sc = wv.scratch + (__mul24(lane, W) + q) * 4;
-                uint32_t a = sc[0], b = sc[1], c = sc[2];
-                freec += (int)(a & 0xffff);
-                F += (int)(a >> 16);
-                U += (int)(b & 0xffff);
-                int m = (int)(b >> 16);
-                ml = m > ml ? m : ml;
-                int lo = (int)(c & 0xffff), hi = (int)(c >> 16);
-                lmin = lo < lmin ? lo : lmin;
-                lmax = hi > lmax ? hi : lmax;
-            }
+        if (link_lane) {
             int nspan = U > 1 ? lmax - lmin : 0, ngaps = U > 1 ? U - 1 : 0;
             int old = wv.lint[link];
             wv.lint[link] = nspan | (ngaps << 16);
@@ -492,14 +495,14 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
             dgaps = ngaps - (old >> 16);
         }
         for (int q = 0; q < nl; ++q) {
-            sum_span += __builtin_amdgcn_readlane(dspan, q);
-            sum_gaps += __builtin_amdgcn_readlane(dgaps, q);
+            sum_span += __builtin_amdgcn_readlane(dspan, q * 8);
+            sum_gaps += __builtin_amdgcn_readlane(dgaps, q * 8);
         }
         const bool graph_now = GRAPH && last_chunk;
         if (graph_now) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
-        // ---- phase B (floats): links on lanes < nl, graph throughput / compactness on lanes 62 / 63
+        // ---- floats: links on their group's first lane, graph throughput / compactness on lanes 62 / 63
         if ((LINKF || graph_now) && now > 0) {
-            const bool is_link = LINKF && lane < nl;
+            const bool is_link = LINKF && link_lane;
             const bool is_graph = graph_now && lane >= 62;
             if (is_link || is_graph) {
                 double *l_util = wv.lst, *l_ef = wv.lst + E, *l_c = wv.lst + 2 * E, *l_lu = wv.lst + 3 * E;
@@ -535,7 +538,7 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                 }
             }
         }
-        if (LINKF && lane < nl) wv.lst[3 * E + link] = now;
+        if (LINKF && link_lane) wv.lst[3 * E + link] = now;
         wave_sync();
         if (graph_now && lane == 0) wv.wsc->g_lu = now;
         wave_sync();
