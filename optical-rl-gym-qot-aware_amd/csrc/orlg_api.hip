@@ -376,7 +376,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     p.l_hist = off; off = up16(off + 4 * NBR * 4);
     p.lint_stride = (E + 3) & ~3;
     p.l_lint = off; off = up16(off + p.lint_stride * 4);
-    p.l_scratch = off; off = up16(off + 64 * 16);
+    p.l_scratch = off; off = up16(off + (int)sizeof(OrlgEnvScalars));  // staging row of the scalar record
     p.l_wsc = off; off = up16(off + (int)sizeof(OrlgWaveScalars));
     p.l_ring = off; off = up16(off + ORLG_RING * (8 + 8 + 4));
     p.l_wave_bytes = off;
@@ -423,6 +423,15 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         p.t_brcum = put(c->bit_rate_cum, (size_t)NBR * 8);
         p.t_srccum = put(c->src_cum, (size_t)N * 8);
         p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
+        if (c->stats_level >= ORLG_STATS_FULL) {
+            // quotients of _update_link_stats with a small integer range (rmsa_env.py:575-600): the host's IEEE division
+            std::vector<double> divs(S + 1), inv(S / 2 + 2);
+            for (int k = 0; k <= S; k++) divs[k] = (double)k / (double)S;
+            inv[0] = 0.0;
+            for (size_t k = 1; k < inv.size(); k++) inv[k] = 1.0 / (double)k;
+            p.t_divs = put(divs.data(), divs.size() * 8);
+            p.t_inv = put(inv.data(), inv.size() * 8);
+        }
         p.tab_bytes = (int32_t)blob.size();
         p.l_outs = p.tab_bytes;
         p.l_shared_bytes = p.tab_bytes + up16(ORLG_NUM_OUTS * 8);

@@ -90,6 +90,8 @@ struct OrlgParams {
     int32_t t_brcum;          // double [NBR]
     int32_t t_srccum;         // double [N]
     int32_t t_dstcum;         // double [N*N]
+    int32_t t_divs;           // double [S+1]        k / S   (link utilization: exact IEEE quotients, built on the host)
+    int32_t t_inv;            // double [S/2+2]      1 / k   (link compactness)
     // per-call IO
     const int32_t *actions;
     void *outs[ORLG_NUM_OUTS];

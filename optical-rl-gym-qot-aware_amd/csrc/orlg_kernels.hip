@@ -101,6 +101,7 @@ struct Tab {  // topology tables staged in LDS (shared by the waves of a workgro
     const uint16_t *nslots;
     const int32_t *bit_rates;
     const double *br_cum, *src_cum, *dst_cum;
+    const double *div_s, *inv_k;   // k / S and 1 / k tables (full statistics)
     const u64 *outs;
 };
 
@@ -128,6 +129,8 @@ DEV Tab make_tab(unsigned char *smem, const OrlgParams &p) {
     tb.br_cum = reinterpret_cast<const double *>(smem + p.t_brcum);
     tb.src_cum = reinterpret_cast<const double *>(smem + p.t_srccum);
     tb.dst_cum = reinterpret_cast<const double *>(smem + p.t_dstcum);
+    tb.div_s = reinterpret_cast<const double *>(smem + p.t_divs);
+    tb.inv_k = reinterpret_cast<const double *>(smem + p.t_inv);
     tb.outs = reinterpret_cast<const u64 *>(smem + p.l_outs);
     return tb;
 }
@@ -514,11 +517,11 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                     const u64 *row = wv.occ + link * W;
                     bool first_free = row[0] & 1ull;
                     bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
-                    cur0 = ORLG_FDIV((double)(S - freec), (double)S);
+                    cur0 = tb.div_s[S - freec];  // (S - free) / S
                     if (freec > 0) {
                         int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
                         cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
-                        cur2 = U > 1 ? ORLG_FDIV((double)(lmax - lmin), (double)(S - freec)) * ORLG_FDIV(1.0, (double)U) : 1.0;
+                        cur2 = U > 1 ? ORLG_FDIV((double)(lmax - lmin), (double)(S - freec)) * tb.inv_k[U] : 1.0;
                     }
                 } else {
                     last_update = wv.wsc->g_lu;
@@ -689,7 +692,7 @@ DEV void rmsa_body(const OrlgParams &p) {
         }
     }
     wave_sync();
-    // wave-uniform working copies (the scalar record sits in the scratch area until the first statistics pass reuses it)
+    // wave-uniform working copies (the scalar record was staged through the scratch row)
     const OrlgEnvScalars *gs = reinterpret_cast<const OrlgEnvScalars *>(wv.scratch);
     int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
     double pf_iat = 0.0, pf_ht = 0.0;   // direct mode: the ring entry of the launch's first arrival, requested early
