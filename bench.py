@@ -27,6 +27,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 ENV_KW = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000)
 TOPOLOGY = "nsfnet_chen_5-paths_6-modulations"
+# --mixed (BASELINE configs[4]): one topology group per rank, rank r takes MIXED[r % 3]; "JPN48" is not shipped with the
+# reference, jpn12 stands in
+MIXED = ("nsfnet_chen_5-paths_6-modulations", "jpn12_5-paths_6-modulations", "us14_3-paths_6-modulations")
 
 
 def algorithmic_bytes_per_env_step(topo, W):
@@ -109,6 +112,7 @@ def main():
     ap.add_argument("--policy", default="sap_ff")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra B=65536 measurement (north_star batch)")
+    ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -131,7 +135,8 @@ def main():
     from conftest import load_topology
     from optical_rl_gym_amd import BatchedRMSAEnv
 
-    topo = load_topology(TOPOLOGY)
+    topo_name = MIXED[rank % 3] if args.mixed else TOPOLOGY
+    topo = load_topology(topo_name)
     B = args.batch
     from optical_rl_gym_amd.distributed import allreduce_stats, shard_base_seed
     env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=shard_base_seed(10, B, rank), stats_level=args.stats, device=local_rank)
@@ -205,8 +210,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 bitmap + f64 statistics",
             "data": "synthetic (reference's Poisson traffic generator run on the device, seeds 10+i)",
-            "config": {"workload": f"RMSA-v0 NSFNET 320 slots load 50, batch {B} envs per GPU, {args.policy} on device, "
-                                   f"stats={args.stats}, {args.chunk} env-steps per launch",
+            "config": {"workload": (f"RMSA-v0 {'NSFNET/JPN12/US14 (rank mod 3)' if args.mixed else 'NSFNET'} 320 slots load 50, "
+                                    f"batch {B} envs per GPU, {args.policy} on device, "
+                                    f"stats={args.stats}, {args.chunk} env-steps per launch"),
                        "batch_per_gpu": B, "global_batch": B * world, "policy": args.policy, "stats_level": args.stats,
                        "chunk": args.chunk, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
