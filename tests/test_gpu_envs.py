@@ -102,3 +102,14 @@ def test_path_mask_for_non_candidate_path():
             for s in (0, 17, 100, 319 - n, 320 - n):
                 assert env.is_path_free(p, s, n) == bool(want[s:s + n].all())
     env.close()
+
+
+def test_make_by_registry_id(nsfnet):
+    """gym.make("RMSA-v0", **env_args) of the reference's scripts -> optical_rl_gym_amd.make."""
+    import optical_rl_gym_amd as pkg
+    env = pkg.make("RMSA-v0", topology=nsfnet, num_spectrum_resources=320, load=50, mean_service_holding_time=25,
+                   episode_length=30, seed=10)
+    assert isinstance(env, pkg.RMSAEnv)
+    obs, reward, done, info = env.step(pkg.shortest_available_path_first_fit(env))
+    assert reward in (0, 1) and "service_blocking_rate" in info
+    env.close()

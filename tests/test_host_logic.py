@@ -109,3 +109,14 @@ def test_selection_tables_match_cpython_choices():
         want_d = r1.choices(range(5), weights=p)[0]
         got_d = bisect.bisect(list(dst_cum[want]), r2.random() * (dst_cum[want][-1] + 0.0), 0, 4)
         assert want_d == got_d and got_d != want
+
+
+def test_registry_ids_resolve():
+    """optical_rl_gym/__init__.py:3-31: the ids of the hot-path environments resolve to the single-env views."""
+    import optical_rl_gym_amd as pkg
+    assert pkg.env_class("RMSA-v0") is pkg.RMSAEnv
+    assert pkg.env_class("DeepRMSA-v0") is pkg.DeepRMSAEnv
+    assert pkg.env_class("PhyRMSA-v0") is pkg.PhyRMSAEnv
+    with pytest.raises(KeyError):
+        pkg.env_class("RWA-v0")   # out of scope (SURVEY section 2)
+    assert pkg.register_with_gym() is None or hasattr(pkg.register_with_gym(), "make")
