@@ -744,7 +744,7 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
     if (lds > 160 * 1024) return fail(ORLG_ERR_INVALID, "observation of %d values does not fit the LDS next to the tables", p.obs_dim);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int nblocks = (p.B + wpb - 1) / wpb;
-    if (nblocks > 4 * e->num_cu) nblocks = 4 * e->num_cu;   // a few workgroups per CU, each striding over its environments
+    if (nblocks > 4 * e->num_cu) nblocks = 4 * e->num_cu;   // a few workgroups per CU, each wave striding over its environments
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds, e->stream, p);
     HIP_TRY(hipGetLastError());

@@ -1087,8 +1087,9 @@ __global__ __launch_bounds__(ORLG_WAVE) void orlg_path_masks_kernel(const OrlgPa
 }
 
 // DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env.  One wave per env at a time: the grid is sized to the
-// device and strides over the environments (the topology tables are staged once per workgroup); the vector is put
-// together in LDS and leaves as one coalesced row of obs_dim doubles.
+// device and strides over the environments (the topology tables are staged once per workgroup).  The per-path integers
+// (block starts / lengths, slots needed, free slots, free runs) are found with wave-uniform scans and parked in LDS; then
+// lane i evaluates element i of the vector -- one fp64 division sequence for all elements -- and the row leaves coalesced.
 template <int W>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deeprmsa_obs_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1099,19 +1100,22 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
     const int occ_bytes = (p.NW * 8 + 15) & ~15, obs_bytes = (p.obs_dim * 8 + 15) & ~15;
     unsigned char *wb = smem + p.l_shared_bytes + (size_t)wib * (occ_bytes + obs_bytes);
     u64 *occ = reinterpret_cast<u64 *>(wb);
-    double *out = reinterpret_cast<double *>(wb + occ_bytes);
+    int *opa = reinterpret_cast<int *>(wb + occ_bytes);   // [obs_dim] integer operand of element i
+    int *opb = opa + p.obs_dim;                            // [obs_dim] second operand (free runs) where needed
     const int N = p.N, K = p.K, S = p.S, J = p.j;
+    const int PW = 2 * J + 3, head = 1 + 2 * N;
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const bool wide = (p.NW & 1) == 0;
     for (int env = blockIdx.x * (int)(blockDim.x >> 6) + wib; env < p.B; env += n_waves) {
-        const u64 *g = p.occ + (size_t)env * p.NW;
         const OrlgEnvScalars *sc = p.scal + env;
         const int src = sc->req_src, dst = sc->req_dst, br = sc->req_br;
-        for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
+        if (wide) copy_words(occ, p.occ + (size_t)env * p.NW, p.NW * 8, lane);
+        else {
+            const u64 *g = p.occ + (size_t)env * p.NW;
+            for (int i = lane; i < p.NW; i += 64) occ[i] = g[i];
+        }
         wave_sync();
         const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
-        // bit rate + one-hot endpoints
-        if (lane == 0) out[0] = (double)tb.bit_rates[br] / 100;
-        for (int i = lane; i < 2 * N; i += 64) out[1 + i] = (i == mn || i == N + mx) ? 1.0 : 0.0;
         const int base = tb.pair_base[src * N + dst];
         const int pp = lane / W, pw = lane - pp * W;
         u64 acc = 0ull;
@@ -1119,21 +1123,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
         int my_se = 0;
         if (lane < K) my_se = tb.recs[base + lane].se;
         int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
-        const int PW = 2 * J + 3;
-        double *sp = out + 1 + 2 * N;
         for (int idp = 0; idp < K; ++idp) {
             u64 x[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
             const int n = __builtin_amdgcn_readlane(my_n, idp);
-            double *row = sp + idp * PW;
+            int *row = opa + head + idp * PW;
             for (int b = 0; b < J; ++b) {
                 int len = 0;
                 int s0 = find_block<W>(x, n, b, lane, &len);
-                if (lane == 0) {
-                    row[2 * b] = s0 >= 0 ? 2 * ((double)s0 - 0.5 * S) / S : -1.0;
-                    row[2 * b + 1] = s0 >= 0 ? ((double)len - 8) / 8 : -1.0;
-                }
+                if (lane == 0) { row[2 * b] = s0; row[2 * b + 1] = s0 >= 0 ? len : -1; }
             }
             int total = 0, runs = 0;
 #pragma unroll
@@ -1143,14 +1142,43 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
                 runs += popc64(x[w] & ~((x[w] << 1) | carry));
             }
             if (lane == 0) {
-                row[2 * J] = ((double)n - 5.5) / 3.5;
-                row[2 * J + 1] = 2 * ((double)total - 0.5 * S) / S;
-                row[2 * J + 2] = runs > 0 ? ((double)total / (double)runs - 4) / 4 : -1.0;
+                row[2 * J] = n; row[2 * J + 1] = total; row[2 * J + 2] = total;
+                opb[head + idp * PW + 2 * J + 2] = runs;
             }
         }
         wave_sync();
         double *gout = p.o_obs + (size_t)env * p.obs_dim;
-        for (int i = lane; i < p.obs_dim; i += 64) gout[i] = out[i];
+        const int br_val = tb.bit_rates[br];
+        for (int i = lane; i < p.obs_dim; i += 64) {
+            // element i = num / den (one division for every kind of element), optionally followed by (q - 4) / 4
+            double num = 0.0, den = 1.0, res;
+            bool fixed = false, tail = false;
+            double fixed_val = 0.0;
+            if (i == 0) {
+                num = (double)br_val; den = 100.0;                                   // bit_rate / 100
+            } else if (i < head) {
+                fixed = true; fixed_val = (i - 1 == mn || i - 1 == N + mx) ? 1.0 : 0.0;   // one-hot endpoints
+            } else {
+                const int r = i - head, c = r % PW;
+                const int v = opa[i];
+                if (c < 2 * J) {
+                    if (v < 0) { fixed = true; fixed_val = -1.0; }
+                    else if ((c & 1) == 0) { num = 2 * ((double)v - 0.5 * S); den = (double)S; }   // 2 * (start - S/2) / S
+                    else { num = (double)v - 8; den = 8.0; }                                        // (length - 8) / 8
+                } else if (c == 2 * J) {
+                    num = (double)v - 5.5; den = 3.5;                                               // (slots - 5.5) / 3.5
+                } else if (c == 2 * J + 1) {
+                    num = 2 * ((double)v - 0.5 * S); den = (double)S;                               // 2 * (free - S/2) / S
+                } else {
+                    const int runs = opb[i];
+                    if (runs > 0) { num = (double)v; den = (double)runs; tail = true; }              // (free / runs - 4) / 4
+                    else { fixed = true; fixed_val = -1.0; }
+                }
+            }
+            res = num / den;
+            if (tail) res = (res - 4) / 4;
+            gout[i] = fixed ? fixed_val : res;
+        }
         wave_sync();
     }
 }
