@@ -273,7 +273,7 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.t_srccum = put(c->src_cum, (size_t)N * 8);
         p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
         p.t_pairrow = put(c->pair_table_row, (size_t)N * N * 4);
-        p.t_adjoff = put(c->adj_off, (size_t)(t->num_paths + 1) * 4);
+        p.use_masks = E <= 32 ? 1 : 0;
         const int nadj = c->adj_off[t->num_paths];
         std::vector<uint16_t> adj(nadj > 0 ? nadj : 1, 0);
         int wsum_max = 0;
@@ -288,7 +288,17 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
             wsum_max = ws > wsum_max ? ws : wsum_max;
         }
         if (wsum_max > 127) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "cut metric range %d exceeds the 8-bit score field", wsum_max); }
+        p.t_adjoff = put(c->adj_off, (size_t)(t->num_paths + 1) * 4);
         p.t_adj = put(adj.data(), adj.size() * 2);
+        p.t_masks = 0;
+        if (p.use_masks) {
+            std::vector<OrlgPathMasks> masks(t->num_paths);
+            for (int g = 0; g < t->num_paths; g++) {
+                masks[g].path = 0u;
+                for (int i = 0; i < recs[g].hops; i++) masks[g].path |= 1u << recs[g].link[i];
+            }
+            p.t_masks = put(masks.data(), masks.size() * sizeof(OrlgPathMasks));
+        }
         std::vector<double> sq((size_t)E * E + 1);
         for (size_t k = 0; k < sq.size(); k++) sq[k] = std::sqrt((double)k);
         p.t_sqrt = put(sq.data(), sq.size() * 8);

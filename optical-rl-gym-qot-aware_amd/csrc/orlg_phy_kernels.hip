@@ -82,7 +82,8 @@ struct OrlgPhyParams {
     // shared tables
     const unsigned char *tables;   // blob staged into LDS
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
-        t_plen, t_pathpair;
+        t_plen, t_pathpair, t_masks;
+    int32_t use_masks, pad_masks;   // E <= 32: link sets as 32-bit masks (OrlgPathMasks) instead of the adjacency CSR
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
     const double *gsnr_t;   // [num_rows*K][cpad]
     // per-call IO
@@ -100,7 +101,12 @@ struct PhyWaveScalars {  // LDS
     int32_t q_overflow, counted_moves, counted_moves_groom, counted_defrag_cycles;
 };
 
+// the links of one path record as a bit mask over the link index (networks of at most 32 links: US14, NSFNET, JPN12):
+// the RSS metric works on one channel's column along the link axis as a 32-bit vector
+struct OrlgPathMasks { uint32_t path; };
+
 struct PhyTab {
+    const OrlgPathMasks *masks;
     const int32_t *pair_base;
     const OrlgPathRec *recs;
     const int32_t *bit_rates;
@@ -128,20 +134,61 @@ DEV PhyTab make_phy_tab(unsigned char *smem, const OrlgPhyParams &p) {
     tb.sqrt_tab = reinterpret_cast<const double *>(smem + p.t_sqrt);
     tb.path_len = reinterpret_cast<const double *>(smem + p.t_plen);
     tb.path_pair = reinterpret_cast<const uint16_t *>(smem + p.t_pathpair);
+    tb.masks = reinterpret_cast<const OrlgPathMasks *>(smem + p.t_masks);
     tb.outs = reinterpret_cast<const uint64_t *>(smem + p.l_outs);
     return tb;
+}
+
+
+// ---- columns as bit vectors (E <= 32).  The RSS metric and the per-step totals look at one channel's column along the LINK
+// axis: bit l of col = available_channels[link l][channel].  Built once per word, a column serves every candidate path:
+//   rss:  sqrt(sum len^2) / (sum len + 1) over the runs of ones of col (after: col & ~path, released: col | path)
+//   cuts of a column (free runs) = popc(col & ~(col << 1))
+// (the cut metric of a candidate only reads the few links adjacent to its path: it keeps its adjacency lists)
+template <int W>
+DEV uint32_t column_bits(const u64 *occ, int E, int w, int lane) {  // lane = channel within word w
+    uint32_t col = 0u;
+    for (int l = 0; l < E; ++l) col |= (uint32_t)((occ[__mul24(l, W) + w] >> lane) & 1ull) << l;
+    return col;
+}
+DEV uint32_t lane_column_bits(const u64 *occ, int E, int W, int ch) {  // any channel, per lane
+    uint32_t col = 0u;
+    const int w = ch >> 6, b = ch & 63;
+    for (int l = 0; l < E; ++l) col |= (uint32_t)((occ[__mul24(l, W) + w] >> b) & 1ull) << l;
+    return col;
+}
+DEV double rss_of_column(uint32_t col, const double *sqrt_tab) {
+    const int sm = __builtin_popcount(col);
+    int sq = 0;
+    while (col) {
+        col >>= __builtin_ctz(col);
+        const uint32_t inv = ~col;
+        const int len = inv ? __builtin_ctz(inv) : 32;
+        sq += len * len;
+        col = len >= 32 ? 0u : col >> len;
+    }
+    return ORLG_FDIV(sqrt_tab[sq], (double)(sm + 1));
 }
 
 // _calculate_total_cuts (phy_rmsa_env.py:1195-1203) and calculate_total_r_spatial (:1110-1121): run-length statistics of
 // every channel's column along the link axis.  Lane = channel; the link loop is wave-uniform.
 template <int W>
 DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C, int lane, double *scratch_d, bool want_cuts,
-                            bool want_rss, double &cuts_out, double &rss_out) {
+                            bool want_rss, bool use_masks, double &cuts_out, double &rss_out) {
     int total_runs = 0;
     for (int w = 0; w < W; ++w) {
         const int ch = 64 * w + lane;
         int runs = 0, cur = 0, sumsq = 0, sum = 0;
         int prev = 0;
+        if (use_masks) {
+            const uint32_t col = column_bits<W>(occ, E, w, lane);
+            runs = __builtin_popcount(col & ~(col << 1));
+            if (want_rss) scratch_d[ch] = ch < C ? rss_of_column(col, sqrt_tab) : 0.0;
+            if (ch >= C) runs = 0;
+            for (int off = 32; off > 0; off >>= 1) runs += __shfl_xor(runs, off);
+            total_runs += runs;
+            continue;
+        }
         for (int l = 0; l < E; ++l) {
             int b = (int)((occ[l * W + w] >> lane) & 1ull);
             runs += b & (prev ^ 1);
@@ -183,7 +230,24 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
 //   along the link axis, after taking the channel on the path's links minus before.
 template <int W>
 DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, const uint8_t *mrow,
-                         int lane, int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W]) {
+                         int lane, int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W],
+                         const uint32_t (&cols)[W], const double *r0w /* LDS [W][64]: RSS of the lane's columns as they are */) {
+    if (p.use_masks && metric_mode == 1) {
+        // the columns and their RSS as they are were built once for all candidate paths: phy_columns
+        const uint32_t pmask = (uint32_t)uni((int)tb.masks[gid].path);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const u64 x = readlane64(acc, idp * W + w);
+            lv[w] = -1; mt[w] = 0.0;
+            if (x != 0ull) {
+                const int ch = 64 * w + lane;
+                const bool fr = ((x >> lane) & 1ull) && ch < p.C;
+                const double metric = rss_of_column(cols[w] & ~pmask, tb.sqrt_tab) - r0w[w * 64 + lane];
+                if (fr) { lv[w] = flat_level ? 0 : (int)mrow[ch]; mt[w] = metric; }
+            }
+        }
+        return;
+    }
     const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
     // links of the path as a bit set (E <= 255: four words)
     const OrlgPathRec *rec = tb.recs + gid;
@@ -230,6 +294,20 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
                 metric = r1 - r0;
             }
             if (fr) { lv[w] = flat_level ? 0 : level; mt[w] = metric; }
+        }
+    }
+}
+
+// the lane's channel columns of every word, built once per request for all candidate paths (mask mode only)
+template <int W>
+DEV void phy_columns(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, int lane, int metric_mode, uint32_t (&cols)[W],
+                     double *r0w /* LDS [W][64] */) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        cols[w] = 0u;
+        if (p.use_masks && metric_mode == 1) {
+            cols[w] = column_bits<W>(occ, p.E, w, lane);
+            r0w[w * 64 + lane] = rss_of_column(cols[w], tb.sqrt_tab);   // read back by the same lane only
         }
     }
 }
@@ -360,7 +438,12 @@ DEV int lane_cut_sum(const u64 *occ, const PhyTab &tb, int gid, int ch, int W) {
 
 // calculate_r_spatial on ONE lane (phy_rmsa_env.py:1085-1108): RSS of channel ch's column with the path's links forced
 // to `force` (0: taken, 1: released = defrag_flag) minus the RSS of the column as it is
-DEV double lane_rss_delta(const u64 *occ, const double *sqrt_tab, const OrlgPathRec *rec, int ch, int E, int W, int force) {
+DEV double lane_rss_delta(const u64 *occ, const double *sqrt_tab, const OrlgPathRec *rec, int ch, int E, int W, int force,
+                          const OrlgPathMasks *masks /* nullptr: no masks */) {
+    if (masks) {
+        const uint32_t col = lane_column_bits(occ, E, W, ch);
+        return rss_of_column(force ? col | masks->path : col & ~masks->path, sqrt_tab) - rss_of_column(col, sqrt_tab);
+    }
     u64 pm[4] = {0ull, 0ull, 0ull, 0ull};
     const int hops = rec->hops;
     for (int h = 0; h < hops; ++h) {
@@ -404,8 +487,8 @@ DEV u64 wave_min_u64(u64 v) {
 //     its path and moves there (_move, :662-697) when placing costs less than releasing gains.
 template <int W>
 DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
-                             uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, int n_running, int &next_seq,
-                             double current_time, int req_src, int req_dst, int lane) {
+                             uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
+                             int &next_seq, double current_time, int req_src, int req_dst, int lane) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
@@ -541,7 +624,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     const int raw = (int)r->ch[j];
                     if (!(raw & (1 << 14))) {  // only channels the service fills are reallocated
                         ch = raw & 0x1ff;
-                        diff = rss ? lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1) : (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
+                        diff = rss ? lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1, p.use_masks ? tb.masks + my_gid : nullptr) : (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
                         is_c = diff > 0.0;
                     }
                 }
@@ -598,7 +681,9 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
                 int lv[W];
                 double mtr[W];
-                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, false, lv, mtr);
+                uint32_t cols[W];
+                phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
+                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, false, lv, mtr, cols, r0w);
 #pragma unroll
                 for (int w = 0; w < W; ++w) lv[w] = lv[w] == level ? 0 : -1;
                 int l0, c0;
@@ -795,6 +880,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     const bool first_row = policy == ORLG_PHY_POLICY_SAPFF || policy == ORLG_PHY_POLICY_SAPBM;
                     const int pp = lane / W, pw = lane - pp * W;
                     const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
+                    uint32_t cols[W];
+                    double *r0w = scratch_d;   // free until the per-step outputs
+                    phy_columns<W>(occ, tb, p, lane, metric_mode, cols, r0w);
                     int head_level[ORLG_PHY_MAX_K];
                     double head_metric[ORLG_PHY_MAX_K];
                     unsigned alive = 0;
@@ -809,7 +897,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         if (idp < K) {
                             int lv[W];
                             double mtr[W];
-                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr);
+                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr, cols, r0w);
                             int bl, bc;
                             double bm;
                             phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
@@ -843,7 +931,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             for (int w = 0; w < W; ++w) { lv[w] = keep_lv[w]; mtr[w] = keep_mt[w]; }
                             keep_idp = -1;
                         } else {
-                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr);
+                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w);
                         }
                         int unassigned = demand;
                         nsel = 0;
@@ -1016,7 +1104,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 const size_t o = (size_t)t * p.B + env;
                 double cuts = 0.0, rss = 0.0;
                 const bool want_c = om & (1 << ORLG_PHY_OUT_CUTS), want_r = om & (1 << ORLG_PHY_OUT_RSS);
-                if (want_c || want_r) phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, want_c, want_r, cuts, rss);
+                if (want_c || want_r) phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, want_c, want_r, p.use_masks != 0, cuts, rss);
                 if (om & (1 << ORLG_PHY_OUT_CHANNELS)) {
                     int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CHANNELS]) + o * ORLG_PHY_MAX_CH;
                     if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_ch[lane] : (int16_t)-1;
@@ -1169,7 +1257,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             wave_sync();
             const long long processed = ws->c[0];
             if (processed % p.defrag_period == 0)
-                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, n_running, next_seq, current_time, req_src, req_dst, lane);
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane);
         }
 
         if (p.mode == ORLG_MODE_STEP) {
