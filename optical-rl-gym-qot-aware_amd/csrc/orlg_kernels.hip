@@ -284,18 +284,36 @@ DEV void ext_chain(const u64 (&x)[W], int (&ext)[W]) {
     for (int w = W - 2; w >= 0; --w) ext[w] = (x[w + 1] == ~0ull) ? 64 + ext[w + 1] : ctz64(~x[w + 1]);
 }
 
+// v_ffbl_b32 as the hardware defines it: index of the lowest set bit, 0xffffffff for 0 (__builtin_ctz is undefined there)
+DEV uint32_t ffbl_hw(uint32_t v) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// length of the free run that starts at this lane's slot: t = (~word) >> lane has its lowest set bit at the first used slot at
+// or after the lane; none left in the word (t == 0) -> the run reaches the word's end and goes on for `rest - (64 - lane)`
+// slots in the next words.  ffbl(0) = 0xffffffff keeps the "none" case out of both minima without a select.
+DEV int free_run_length(u64 t, int rest /* (64 - lane) + extension into the next words */) {
+    const uint32_t a = ffbl_hw((uint32_t)t), b = ffbl_hw((uint32_t)(t >> 32)) | 32u;
+    const uint32_t c = a < b ? a : b;
+    return (int)(c < (uint32_t)rest ? c : (uint32_t)rest);
+}
+
 // smallest s in [0, limit) with slots [s, s+n) free, or -1 (rmsa_env.py:860-871, 908-913)
 template <int W>
 DEV int first_fit(const u64 (&x)[W], int n, int limit, int lane) {
     if (limit <= 0) return -1;
     int ext[W];
     ext_chain<W>(x, ext);
+    const int to_end = 64 - lane;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         if (x[w] != 0ull && 64 * w < limit) {
-            u64 t = (~x[w]) >> lane;
-            int len = t ? ctz64(t) : (64 - lane) + ext[w];
-            u64 m = ballot(len >= n && (64 * w + lane) < limit);
+            const int len = free_run_length((~x[w]) >> lane, to_end + ext[w]);
+            // start slots below the limit: a wave-uniform lane mask, no per-lane compare
+            const int below = limit - 64 * w;
+            const u64 ok = below >= 64 ? ~0ull : ((1ull << below) - 1ull);
+            const u64 m = ballot(len >= n) & ok;
             if (m) return 64 * w + ctz64(m);
         }
     }
@@ -312,9 +330,8 @@ DEV int find_block(const u64 (&x)[W], int n, int b, int lane, int *len_out) {
         if (x[w] != 0ull) {
             u64 carry = w > 0 ? (x[w > 0 ? w - 1 : 0] >> 63) : 0ull;
             u64 starts = x[w] & ~((x[w] << 1) | carry);
-            u64 t = (~x[w]) >> lane;
-            int len = t ? ctz64(t) : (64 - lane) + ext[w];
-            u64 m = ballot(((starts >> lane) & 1ull) && len >= n);
+            int len = free_run_length((~x[w]) >> lane, (64 - lane) + ext[w]);
+            u64 m = ballot(len >= n) & starts;   // run starts: a wave-uniform lane mask
             int cnt = popc64(m);
             if (b < cnt) {
                 for (int q = 0; q < b; ++q) m &= m - 1;
@@ -477,8 +494,7 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                 while (st) {
                     int b = ctz64(st);
                     st &= st - 1;
-                    u64 t = (~x) >> b;
-                    int len = t ? ctz64(t) : 64 - b + e;
+                    int len = free_run_length((~x) >> b, 64 - b + e);
                     ml = len > ml ? len : ml;
                 }
             }
