@@ -181,6 +181,13 @@ int orlg_deeprmsa_obs_dim(orlg_env *env);
 int orlg_simple_matrix_observation(orlg_env *env, uint8_t *out);
 int orlg_simple_matrix_obs_dim(orlg_env *env);
 
+/* checkpoint / resume (the reference has none for environment state): the complete simulation state
+ * of the handle -- occupancy, release queue, RNG, pending requests, counters, statistics -- as one flat blob of
+ * orlg_state_size() bytes (host or device buffer).  A blob only fits a handle created with the same arguments. */
+int64_t orlg_state_size(orlg_env *env);
+int orlg_save_state(orlg_env *env, void *buffer);
+int orlg_load_state(orlg_env *env, const void *buffer);
+
 /* sum of all B counter records + accepted/processed, for multi-GPU statistics: out[0..7] = orlg_counters summed,
  * out[8] = total episodes done, out[9] = B.  The caller all-reduces this vector (RCCL, SUM). */
 int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */);
@@ -275,6 +282,10 @@ int orlg_phy_get_episode_stats(orlg_phy_env *env, orlg_phy_episode_stats *out /*
 /* topology.graph["available_channels"] as a bitmap [B][E][W] uint64 */
 int orlg_phy_get_occupancy(orlg_phy_env *env, uint64_t *out);
 int orlg_phy_reduce_counters(orlg_phy_env *env, int64_t *out /* [16] as orlg_reduce_counters */);
+/* checkpoint / resume, as orlg_save_state */
+int64_t orlg_phy_state_size(orlg_phy_env *env);
+int orlg_phy_save_state(orlg_phy_env *env, void *buffer);
+int orlg_phy_load_state(orlg_phy_env *env, const void *buffer);
 /* env.channel_state[src_id, dst_id, k-path] of ONE env (phy_rmsa_env.py:117-125): entries [N*N*K][capacity] packed
  * channel | used << 9 | free << 14 | capacity << 19 (100 Gb/s units) in list order, lengths [N*N*K]; returns capacity */
 int orlg_phy_get_channel_state(orlg_phy_env *env, int32_t env_index, uint32_t *entries, uint8_t *lengths);

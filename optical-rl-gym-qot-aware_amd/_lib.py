@@ -127,6 +127,11 @@ def load(build_if_missing=True):
                  "orlg_phy_get_num_running", "orlg_phy_get_episode_stats", "orlg_phy_get_occupancy",
                  "orlg_phy_reduce_counters"):
         getattr(L, name).argtypes = [vp, vp]
+    for name in ("orlg_state_size", "orlg_phy_state_size"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i64
+    for name in ("orlg_save_state", "orlg_load_state", "orlg_phy_save_state", "orlg_phy_load_state"):
+        getattr(L, name).argtypes = [vp, vp]
     L.orlg_phy_get_channel_state.argtypes = [vp, i32, vp, vp]
     L.orlg_phy_channel_state_capacity.argtypes = [vp]
     L.orlg_host_log.argtypes = [C.c_double]
@@ -146,7 +151,8 @@ EXPORTED_SYMBOLS = [
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
     "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_phy_get_channel_state",
-    "orlg_phy_channel_state_capacity", "orlg_gn_osnr",
+    "orlg_phy_channel_state_capacity", "orlg_gn_osnr", "orlg_state_size", "orlg_save_state", "orlg_load_state",
+    "orlg_phy_state_size", "orlg_phy_save_state", "orlg_phy_load_state",
 ]
 
 

@@ -260,6 +260,20 @@ class BatchedRMSAEnv:
         r = self.run("path_ff_external", 1, actions=paths, outputs=outputs)
         return {k: v[0] for k, v in r.items()}
 
+    def save_state(self):
+        """Snapshot of the complete simulation state of the batch (a uint8 array): checkpoint / resume, env cloning."""
+        n = self.L.orlg_state_size(self.h)
+        if n < 0:
+            _lib.check(int(n))
+        buf = np.empty(int(n), np.uint8)
+        _lib.check(self.L.orlg_save_state(self.h, _ptr(buf)))
+        return buf
+
+    def load_state(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        assert buf.size == self.L.orlg_state_size(self.h), "snapshot of a differently configured batch"
+        _lib.check(self.L.orlg_load_state(self.h, _ptr(buf)))
+
     def reduce_counters(self):
         """Summed counters of this shard (raises if a release queue overflowed): the vector a
         multi-GPU job all-reduces."""

@@ -791,6 +791,45 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------------------- checkpoint / resume
+// The whole simulation state of a handle is a handful of flat device arrays: a snapshot is their concatenation.
+struct StatePart { void *ptr; size_t bytes; };
+static std::vector<StatePart> rmsa_state_parts(orlg_env *e) {
+    const OrlgParams &p = e->p;
+    const size_t B = p.B;
+    return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qdesc, B * p.Q * 4}, {p.mt, B * ORLG_MT_N * 4},
+            {p.scal, B * sizeof(OrlgEnvScalars)}, {p.lint, B * p.lint_stride * 4}, {p.hist, B * 4 * p.NBR * 4},
+            {p.lstat, B * 4 * p.E * 8}, {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8},
+            {p.ring_req, B * ORLG_RING * 4}};
+}
+static int state_copy(const std::vector<StatePart> &parts, void *buffer, bool save, int device, hipStream_t stream) {
+    HIP_TRY(hipSetDevice(device));
+    unsigned char *b = static_cast<unsigned char *>(buffer);
+    for (const StatePart &sp : parts) {
+        if (save) HIP_TRY(hipMemcpyAsync(b, sp.ptr, sp.bytes, hipMemcpyDefault, stream));
+        else HIP_TRY(hipMemcpyAsync(sp.ptr, b, sp.bytes, hipMemcpyDefault, stream));
+        b += sp.bytes;
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    return ORLG_OK;
+}
+extern "C" {
+int64_t orlg_state_size(orlg_env *e) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    int64_t n = 0;
+    for (const StatePart &sp : rmsa_state_parts(e)) n += (int64_t)sp.bytes;
+    return n;
+}
+int orlg_save_state(orlg_env *e, void *buffer) {
+    if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
+    return state_copy(rmsa_state_parts(e), buffer, true, e->device, e->stream);
+}
+int orlg_load_state(orlg_env *e, const void *buffer) {
+    if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
+    return state_copy(rmsa_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+}
+}
+
 #ifdef ORLG_SECTIONS
 extern "C" int orlg_debug_sections(unsigned long long *out, int reset) {
     HIP_TRY(hipDeviceSynchronize());

@@ -524,6 +524,26 @@ int orlg_phy_get_occupancy(orlg_phy_env *e, uint64_t *out) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     return ORLG_OK;
 }
+static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
+    const OrlgPhyParams &p = e->p;
+    const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
+    return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
+            {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists}};
+}
+int64_t orlg_phy_state_size(orlg_phy_env *e) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    int64_t n = 0;
+    for (const StatePart &sp : phy_state_parts(e)) n += (int64_t)sp.bytes;
+    return n;
+}
+int orlg_phy_save_state(orlg_phy_env *e, void *buffer) {
+    if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
+    return state_copy(phy_state_parts(e), buffer, true, e->device, e->stream);
+}
+int orlg_phy_load_state(orlg_phy_env *e, const void *buffer) {
+    if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
+    return state_copy(phy_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+}
 int orlg_phy_channel_state_capacity(orlg_phy_env *e) { return e ? e->p.cs_len : ORLG_ERR_INVALID; }
 int orlg_phy_get_channel_state(orlg_phy_env *e, int32_t env_index, uint32_t *entries, uint8_t *lengths) {
     if (!e || !entries || !lengths) return fail(ORLG_ERR_INVALID, "null argument");

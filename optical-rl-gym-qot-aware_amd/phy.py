@@ -236,6 +236,20 @@ class BatchedPhyRMSAEnv:
             out[(s, d, k)] = [(int(x & 0x1ff), int((x >> 9) & 0x1f), int((x >> 14) & 0x1f), int((x >> 19) & 0x1f)) for x in e]
         return out
 
+    def save_state(self):
+        """Snapshot of the complete simulation state of the batch (a uint8 array): checkpoint / resume, env cloning."""
+        n = self.L.orlg_phy_state_size(self.h)
+        if n < 0:
+            _lib.check(int(n))
+        buf = np.empty(int(n), np.uint8)
+        _lib.check(self.L.orlg_phy_save_state(self.h, _ptr(buf)))
+        return buf
+
+    def load_state(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        assert buf.size == self.L.orlg_phy_state_size(self.h), "snapshot of a differently configured batch"
+        _lib.check(self.L.orlg_phy_load_state(self.h, _ptr(buf)))
+
     def reduce_counters(self):
         a = np.zeros(16, np.int64)
         _lib.check(self.L.orlg_phy_reduce_counters(self.h, _ptr(a)))
