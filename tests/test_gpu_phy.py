@@ -216,3 +216,38 @@ def test_phy_work_queue_more_envs_than_resident_waves(device_log_in_oracle):
         assert env.channel_state(i) == o.channel_state(), i
         o.close()
     env.close()
+
+
+@pytest.mark.parametrize("policy", ["bmfa", "bmfa_rss", "sapbm", "faff"])
+def test_phy_five_paths_synthetic_tables(policy, device_log_in_oracle):
+    """k = 5 candidate paths (the shipped QoT fixtures keep 3 columns): JPN12 with 5 paths and synthetic tables, grooming and
+    defragmentation on, device vs oracle."""
+    topo = load_topology("jpn12_5-paths_6-modulations")
+    rng = np.random.default_rng(12)
+    n = topo.num_nodes
+    pairs = np.array([(a + 1, b + 1) for a in range(n) for b in range(a + 1, n)], np.int32)
+    mod = rng.integers(1, 7, size=(len(pairs), 268, 5)).astype(np.uint8)
+    gsnr = rng.uniform(5.0, 25.0, size=mod.shape)
+    tables = (pairs, mod, gsnr)
+    kw = dict(load=700, mean_service_holding_time=25, episode_length=120, seed=9, grooming=True, defrag_period=8, number_moves=5,
+              metric="rss" if policy == "bmfa_rss" else "cut")
+    env = make_env(topo, tables, kw, 3)
+    tr = env.run(policy, 350, outputs=("act_path", "channels", "channels_used", "accepted", "number_cuts_total", "rss_total_metric",
+                                       "defrag_counters"), auto_reset=True)
+    av, cnt = env.available_channels(), env.counters()
+    assert env.episode_stats()["queue_overflow"].max() == 0
+    for i in range(3):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=9 + i)
+        ot = o.run(policy, 350, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["channels_used"][:, i, :12].astype(np.float64), ot["ch_used"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        assert np.array_equal(tr["rss_total_metric"][:, i], ot["rss_total_metric"]), i
+        assert np.array_equal(tr["defrag_counters"][:, i, 1], ot["num_moves_groom"]), i
+        assert np.array_equal(av[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        assert env.channel_state(i) == o.channel_state(), i
+        o.close()
+    assert (tr["act_path"] >= 3).any()   # paths 4 and 5 are used
+    env.close()
