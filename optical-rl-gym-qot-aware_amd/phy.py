@@ -5,8 +5,8 @@ MI355X: physical layer and virtual ("grooming") layer.  Constructor kwargs are t
 reference's MATLAB object array).
 
 Device policies (``run(policy, ...)``): ``bmfa`` / ``bmfa_rss`` (``phy_rmsa_env.py:1375,1441``; they consult the
-virtual layer only when ``grooming=True``), ``sapff`` / ``bmff`` / ``sapbm`` (``:1676,1317,1254``; they always try
-``use_existing_channels`` first, like the reference) and ``external``.  ``defrag_period`` / ``number_moves`` / ``metric``
+virtual layer only when ``grooming=True``), ``sapff`` / ``bmff`` / ``sapbm`` / ``faff`` / ``faff_rss``
+(``:1676,1317,1254,1508,1572``; they always try ``use_existing_channels`` first, like the reference) and ``external``.  ``defrag_period`` / ``number_moves`` / ``metric``
 switch on the periodic defragmentation (``phy_rmsa_env.py:355-417``), run inside the step kernel.
 """
 from __future__ import annotations

@@ -84,7 +84,7 @@ def load_phy_tables(name):
 
 
 def phy_oracle_from_kwargs(topo, tables, env_kwargs, seed=None, asan=False):
-    """Oracle PhyRMSAEnv from reference-style kwargs (phy_rmsa_env.py:30-58), physical layer only."""
+    """Oracle PhyRMSAEnv from reference-style kwargs (phy_rmsa_env.py:30-58)."""
     import oracle as orc
     from optical_rl_gym_amd import selection_tables
     kw = dict(env_kwargs)

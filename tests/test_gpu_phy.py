@@ -1,5 +1,5 @@
-"""GPU parity of the QoT-aware (PhyRMSA) path, physical layer: device heuristic bmfa(cut) and external actions
-against the oracle (all envs, bit-exact with the device log in the oracle) and the reference's golden traces
+"""GPU parity of the QoT-aware (PhyRMSA) path -- physical and virtual layer, periodic defragmentation: the seven device
+heuristics and external actions against the oracle (all envs, bit-exact with the device log in the oracle) and the reference's golden traces
 (env 0: decisions / counters exactly, time-derived floats to rtol 1e-12)."""
 import numpy as np
 import pytest
