@@ -1,0 +1,59 @@
+"""Error behaviour of the C ABI on the device: limits are refused with ORLG_ERR_INVALID and a message, an exhausted release
+queue / channel_state list / work list is reported as ORLG_ERR_QUEUE_FULL by reduce_counters -- never silently dropped."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, load_phy_tables, load_topology
+from test_gpu_phy import make_env
+from test_gpu_rmsa import make_batched
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rmsa_queue_overflow_is_reported(nsfnet):
+    from optical_rl_gym_amd import OrlgError
+    kw = dict(num_spectrum_resources=320, load=150, mean_service_holding_time=25, episode_length=1000, seed=1)
+    env = make_batched(nsfnet, kw, 16, queue_capacity=64)   # well over 64 services in progress at this load
+    env.run("sap_ff", 3000)
+    with pytest.raises(OrlgError) as ei:
+        env.reduce_counters()
+    assert ei.value.code == -4 and "queue" in str(ei.value)
+    env.close()
+
+
+def test_rmsa_limits_are_refused(nsfnet):
+    from optical_rl_gym_amd import OrlgError
+    for bad in (dict(num_spectrum_resources=513), dict(num_spectrum_resources=0), dict(load=0)):
+        kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, seed=1)
+        kw.update(bad)
+        with pytest.raises((OrlgError, ZeroDivisionError, ValueError, AssertionError)):
+            make_batched(nsfnet, kw, 4).close()
+    with pytest.raises(OrlgError) as ei:
+        make_batched(nsfnet, dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, seed=1), 0)
+    assert ei.value.code == -1
+
+
+def test_phy_small_structures_overflow_is_reported():
+    from optical_rl_gym_amd import OrlgError
+    z, meta = load_golden("phy_us14_s10_sapff")
+    topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
+    env = make_env(topo, tables, dict(meta["env_kwargs"], load=3000), 4, queue_capacity=256)
+    env.run("sapff", 1500, auto_reset=True)
+    assert env.episode_stats()["queue_overflow"].max() != 0
+    with pytest.raises(OrlgError) as ei:
+        env.reduce_counters()
+    assert ei.value.code == -4
+    env.close()
+
+
+def test_phy_level_zero_tables_are_refused():
+    """A level-0 entry would sort FIRST in the reference (uint8 negation, SURVEY 8c caveat 3): refused, not reinterpreted."""
+    from optical_rl_gym_amd import OrlgError
+    z, meta = load_golden("phy_us14_s10_sapff")
+    topo = load_topology(meta["topology"])
+    pairs, mod, gsnr = load_phy_tables(meta["tables"])
+    mod = mod.copy()
+    mod[3, 100, 1] = 0
+    with pytest.raises(OrlgError) as ei:
+        make_env(topo, (pairs, mod, gsnr), meta["env_kwargs"], 2)
+    assert ei.value.code == -1 and "modulation level" in str(ei.value)
