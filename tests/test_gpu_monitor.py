@@ -32,3 +32,35 @@ def test_batched_evaluate_and_monitor_csv(tmp_path):
     assert rows[1][:3] == ["r", "l", "t"] and len(rows) == 2 + 4 * 3
     assert float(rows[2][0]) == r[0, 0] and int(rows[2][1]) == L - 1
     env.close()
+
+
+def test_phy_batched_evaluate_matches_reference_episodes(tmp_path):
+    """The batched PhyRMSA driver + Monitor CSV: per-episode rows = the info dict of each episode's last step in the
+    reference's trace (env 0), for the first episodes of two configurations (one with the periodic defragmentation)."""
+    import csv
+    import optical_rl_gym_amd as pkg
+    from conftest import load_phy_tables
+    from test_gpu_phy import make_env
+    for case, policy in (("phy_us14_s10_bmfa", "bmfa"), ("phy_us14_s10_bmfa_defrag_cut", "bmfa")):
+        z, meta = load_golden(case)
+        topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
+        env = make_env(topo, tables, meta["env_kwargs"], 3)
+        ends = np.nonzero(z["done"])[0]
+        n_ep = min(3, len(ends))
+        path = str(tmp_path / (case + ".monitor.csv"))
+        r, l, info = pkg.evaluate_phy_heuristic_batched(env, policy, n_eval_episodes=n_ep, monitor_path=path)
+        start = 0
+        for e in range(n_ep):
+            t = ends[e]
+            assert r[e, 0] == z["reward"][start:t + 1].sum() and l[e, 0] == t + 1 - start
+            for k in ("number_cuts_total", "rss_total_metric", "total_path_length", "average_path_index", "path_index",
+                      "physical_paths", "episode_service_blocking_rate"):
+                assert info[k][e, 0] == z[k][t], (case, k, e)
+            np.testing.assert_allclose(info["avrage_gsnr"][e, 0], z["avrage_gsnr"][t], rtol=1e-15)
+            if "num_moves" in z.files:
+                assert info["num_moves"][e, 0] == z["num_moves"][t] and info["num_defrag_cycle"][e, 0] == z["num_defrag_cycle"][t]
+            start = t + 1
+        rows = list(csv.reader(open(path)))
+        assert rows[0][0].startswith('#{"t_start"') and rows[1][:3] == ["r", "l", "t"] and len(rows) == 2 + 3 * n_ep
+        assert rows[1][3:] == list(pkg.monitor.PHY_INFO_KEYWORDS)
+        env.close()
