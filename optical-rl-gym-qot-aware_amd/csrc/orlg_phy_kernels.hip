@@ -678,7 +678,17 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const int idp = (gid >= base_cur && gid < base_cur + K) ? gid - base_cur : K - 1;
                 const uint8_t *mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
                 const int level = uni((int)mrow[ch]);
-                const u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
+                u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
+                // only channels of the candidate's modulation level can take it over: words without one are not scored
+                {
+                    u64 mine = 0ull;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const u64 same = ballot((int)mrow[64 * w + lane] == level);
+                        if (lane == w) mine = same;
+                    }
+                    acc &= mine;
+                }
                 int lv[W];
                 double mtr[W];
                 uint32_t cols[W];

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--grooming", action="store_true")
     ap.add_argument("--defrag", action="store_true", help="defrag_period=10, number_moves=10 (tests/test_rmsa_threads_us.py:190-251)")
     ap.add_argument("--metric", default="cut")
+    ap.add_argument("--moves", type=int, default=10, help="number_moves with --defrag")
+    ap.add_argument("--period", type=int, default=10, help="defrag_period with --defrag")
     ap.add_argument("--queue", type=int, default=0, help="queue_capacity (0 = from the load)")
     args = ap.parse_args()
     import torch
@@ -29,7 +31,7 @@ def main():
     pairs, mod, gsnr = load_phy_tables("us14_k3")
     env = BatchedPhyRMSAEnv(topo, args.batch, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=args.load,
                             mean_service_holding_time=25, episode_length=200, seed=10, grooming=args.grooming,
-                            defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None,
+                            defrag_period=args.period if args.defrag else None, number_moves=args.moves if args.defrag else None,
                             metric=args.metric, queue_capacity=args.queue)
     outs = ("number_cuts_total", "rss_total_metric") if args.metrics else ()
 
