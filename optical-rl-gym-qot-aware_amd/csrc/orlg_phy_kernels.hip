@@ -492,30 +492,51 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
+    // the two scans over all running services read the 48-byte records through LDS: a chunk of records is fetched with
+    // coalesced 16-byte loads into the (otherwise idle) per-channel scratch area, then every lane takes its own record
+    constexpr int CHUNK = (W * 64 * 8) / (int)sizeof(OrlgPhySvc) < 64 ? (W * 64 * 8) / (int)sizeof(OrlgPhySvc) : 64;
+    OrlgPhySvc *stage = reinterpret_cast<OrlgPhySvc *>(r0w);
     // ------------------------------------------------------------------ 1. grooming pass
     int n_el = 0;
-    for (int i0 = 0; i0 < n_running; i0 += 64) {
+    for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
+        const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
+            uint4 *dst = reinterpret_cast<uint4 *>(stage);
+            for (int q = lane; q < cnt * 3; q += 64) dst[q] = src[q];
+        }
+        wave_sync();
         const int idx = i0 + lane;
         bool elig = false;
         uint32_t seq = 0;
-        if (idx < n_running) {
-            const OrlgPhySvc *r = grec + idx;
+        if (lane < cnt) {
+            const OrlgPhySvc *r = stage + lane;
             const int gid = r->gid, nch = r->nch;
             seq = r->seq;
-            const int key = svc_key(tb, N, K, gid, r->flags);
-            const int n = gcs_n[key];
-            const uint32_t *lst = gcs + (size_t)key * p.cs_len;
-            for (int j = 0; j < nch && !elig; ++j) {
-                const int raw = r->ch[j];
-                if (raw & (1 << 14)) {
-                    const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
-                    bool sole = false, target = false;
-                    for (int t = 0; t < n; ++t) {
-                        const uint32_t en = lst[t];
-                        if (cs_ch(en) == ch) sole = sole || cs_used(en) == mine;
-                        else target = target || cs_free(en) >= mine;
+            bool any_partial = false;
+            for (int j = 0; j < nch; ++j) any_partial = any_partial || (r->ch[j] & (1 << 14));
+            if (any_partial) {
+                const int key = svc_key(tb, N, K, gid, r->flags);
+                const int n = gcs_n[key];
+                const uint32_t *lst = gcs + (size_t)key * p.cs_len;
+                for (int j = 0; j < nch && !elig; ++j) {
+                    const int raw = r->ch[j];
+                    if (raw & (1 << 14)) {
+                        const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
+                        bool sole = false, target = false;
+                        for (int t = 0; t < n; t += 4) {  // four independent loads per round trip
+                            uint32_t en[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) en[q] = t + q < n ? lst[t + q] : 0u;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (t + q < n) {
+                                    if (cs_ch(en[q]) == ch) sole = sole || cs_used(en[q]) == mine;
+                                    else target = target || cs_free(en[q]) >= mine;
+                                }
+                        }
+                        elig = sole && target;
                     }
-                    elig = sole && target;
                 }
             }
         }
@@ -525,6 +546,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
             if (elig && pos < p.cand_cap) { cand[pos].seq = seq; cand[pos].idx = (uint16_t)idx; }
             n_el += popc64(m);
         }
+        wave_sync();
     }
     if (n_el > p.cand_cap) { overflow = true; n_el = p.cand_cap; }
     int gmoves = 0;
@@ -606,10 +628,17 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     // ------------------------------------------------------------------ 2. physical pass
     if (gmoves <= p.number_moves) {
         int nc = 0;
-        for (int i0 = 0; i0 < n_running; i0 += 64) {
+        for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
+            const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
+                uint4 *dst = reinterpret_cast<uint4 *>(stage);
+                for (int q = lane; q < cnt * 3; q += 64) dst[q] = src[q];
+            }
+            wave_sync();
             const int idx = i0 + lane;
-            const bool act = idx < n_running;
-            const OrlgPhySvc *r = grec + (act ? idx : 0);
+            const bool act = lane < cnt;
+            const OrlgPhySvc *r = stage + (act ? lane : 0);
             const int my_n = act ? (int)r->nch : 0, my_gid = (int)r->gid;
             const uint32_t my_seq = r->seq;
             const double my_arrival = r->arrival;
@@ -639,6 +668,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     nc += popc64(m);
                 }
             }
+            wave_sync();   // the staging area is refilled by the next chunk
         }
         if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
         wave_sync();
