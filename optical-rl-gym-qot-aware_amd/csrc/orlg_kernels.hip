@@ -455,6 +455,31 @@ DEV int group8_max(int v) {
     o = dpp_half_mirror(v); return o > v ? o : v;
 }
 
+// whole-wave maxima with DPP (no LDS crossbar round trips): quad, half row, row, then the two row broadcasts of gfx9 leave the
+// result in lane 63
+DEV int dpp_row_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); }
+DEV int dpp_bcast15(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); }   // rows 1, 3 <- lane 15 of the row before
+DEV int dpp_bcast31(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); }   // rows 2, 3 <- lane 31
+DEV int wave_max_i32(int v) {
+    int o = dpp_xor1(v); v = o > v ? o : v;
+    o = dpp_xor2(v); v = o > v ? o : v;
+    o = dpp_half_mirror(v); v = o > v ? o : v;
+    o = dpp_row_mirror(v); v = o > v ? o : v;
+    o = dpp_bcast15(v); v = o > v ? o : v;
+    o = dpp_bcast31(v); v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#define ORLG_DPP_F64(fn, x) __hiloint2double(fn(__double2hiint(x)), fn(__double2loint(x)))
+DEV double wave_max_f64(double v) {
+    double o = ORLG_DPP_F64(dpp_xor1, v); v = o > v ? o : v;
+    o = ORLG_DPP_F64(dpp_xor2, v); v = o > v ? o : v;
+    o = ORLG_DPP_F64(dpp_half_mirror, v); v = o > v ? o : v;
+    o = ORLG_DPP_F64(dpp_row_mirror, v); v = o > v ? o : v;
+    o = ORLG_DPP_F64(dpp_bcast15, v); v = o > v ? o : v;
+    o = ORLG_DPP_F64(dpp_bcast31, v); v = o > v ? o : v;
+    return readlane_d(v, 63);
+}
+
 template <int W, bool LINKF, bool GRAPH>
 DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
                            int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr) {

@@ -249,6 +249,36 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
         return;
     }
     const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
+    if (metric_mode == 0) {
+        // cut metric of every word at once: the adjacency entries sit on lanes (one LDS read), every entry then costs one
+        // wave-uniform read of its link's W words -- the per-word loop of dependent LDS reads was the latency of this kernel
+        int cutm[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) cutm[w] = 0;
+        for (int j0 = a0; j0 < a1; j0 += 64) {
+            const int cnt = a1 - j0 < 64 ? a1 - j0 : 64;
+            const int adjv = lane < cnt ? (int)tb.adj[j0 + lane] : 0;
+            for (int j = 0; j < cnt; ++j) {
+                const int aw = __builtin_amdgcn_readlane(adjv, j);
+                const int wt = aw >> 8;
+                const u64 *rowp = occ + __mul24(aw & 0xff, W);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const int b = (int)((rowp[w] >> lane) & 1ull);
+                    cutm[w] += wt * (1 - 2 * b);
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const u64 x = readlane64(acc, idp * W + w);
+            const int ch = 64 * w + lane;
+            const bool fr = ((x >> lane) & 1ull) && ch < p.C;
+            lv[w] = -1; mt[w] = 0.0;
+            if (fr) { lv[w] = flat_level ? 0 : (int)mrow[ch]; mt[w] = (double)cutm[w]; }
+        }
+        return;
+    }
     // links of the path as a bit set (E <= 255: four words)
     const OrlgPathRec *rec = tb.recs + gid;
 #pragma unroll
@@ -318,27 +348,21 @@ DEV void phy_row_best(const int (&lv)[W], const double (&mt)[W], int lane, int &
     int L = -1;
 #pragma unroll
     for (int w = 0; w < W; ++w) L = lv[w] > L ? lv[w] : L;
-    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(L, off); L = o > L ? o : L; }
-    L = uni(L);
+    L = wave_max_i32(L);
     level = L; metric = 0.0; channel = -1;
     if (L < 0) return;
-    bool have = false;
-    double M = 0.0;
+    double M = -__longlong_as_double((long long)ORLG_INF_BITS);  // lanes without a channel of that level stay at -inf
 #pragma unroll
     for (int w = 0; w < W; ++w)
-        if (lv[w] == L && (!have || mt[w] > M)) { M = mt[w]; have = true; }
-    for (int off = 32; off > 0; off >>= 1) {
-        double om = __shfl_xor(M, off);
-        int oh = __shfl_xor((int)have, off);
-        if (oh && (!have || om > M)) { M = om; have = true; }
+        if (lv[w] == L && mt[w] > M) M = mt[w];
+    M = wave_max_f64(M);
+    metric = M;
+    // lowest channel among the ties: the first word with a match, its lowest lane
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const u64 m = ballot(lv[w] == L && mt[w] == M);
+        if (m) { channel = 64 * w + ctz64(m); return; }
     }
-    M = readlane_d(M, 0);
-    int Cc = 0x7fffffff;
-#pragma unroll
-    for (int w = 0; w < W; ++w)
-        if (lv[w] == L && mt[w] == M) { int c = 64 * w + lane; Cc = c < Cc ? c : Cc; }
-    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(Cc, off); Cc = o < Cc ? o : Cc; }
-    metric = M; channel = uni(Cc);
 }
 
 // ---- channel_state lists (virtual layer): one list = up to cs_len packed entries, entry i on lane i
@@ -788,6 +812,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     wv.lane = lane; wv.mt = mt;
 
     const int E = p.E, C = p.C, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
+    SEC_DECL
     // work queue (as orlg_rmsa_kernel): long launches draw environments from the ticket counter (the next ticket is drawn
     // while the current environment runs), short ones stride statically
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
@@ -818,6 +843,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
 
+    SEC(1);  // state load
     // ------------------------------------------------------------------ HBM -> LDS
     const OrlgPhyScalars *gs = p.scal + env;
     int n_running = gs->n_running;
@@ -853,6 +879,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
 
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
+        SEC(2);  // policy: virtual layer
         if (p.mode == ORLG_MODE_STEP) {
             const int base = tb.pair_base[req_src * N + req_dst];
             const int row = tb.pair_row[req_src * N + req_dst];
@@ -907,6 +934,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                     if (!served) nsel = 0;
                 }
+                SEC(3);  // policy: row metrics
                 if (!served) {
                     // per path ("row") the free channels ordered by (level desc, metric desc, channel asc)
                     //   bmfa / bmfa_rss: sorted(row, key=(-level, -metric)), row with the best head (level, metric)
@@ -951,6 +979,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             }
                         }
                     }
+                    SEC(4);  // policy: channel selection
                     for (;;) {
                         int best = -1, bl = -1;
                         double bm = 0.0;
@@ -999,6 +1028,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 wave_sync();
             }
 
+            SEC(5);  // provision
             // ========================================================== PhyRMSAEnv.step (phy_rmsa_env.py:272-351)
             bool accepted = false;
             const bool dirbit = req_src > req_dst;
@@ -1138,6 +1168,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
             }
 
+            SEC(6);  // outputs
             // per-step outputs
             if (p.out_mask) {
                 const int om = p.out_mask;
@@ -1182,6 +1213,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             wave_sync();
         }
 
+        SEC(7);  // next arrival
         // ============================================================== _next_service (phy_rmsa_env.py:969-1017)
         if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
             double u[5];
@@ -1204,6 +1236,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 ws->c[0] += 1; ws->c[2] += 1; ws->c[4] += br_val; ws->c[6] += br_val;
                 ws->req_arrival = at; ws->req_holding = ht;
             }
+            SEC(9);  // release: buffer / rebuild
             // ---- release every service with release time <= now in time order (:1009-1017, _release_path :781-861):
             // with the virtual layer the order of simultaneous releases decides who frees a shared channel
             wave_sync();
@@ -1227,6 +1260,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                 }
                 if (victim < 0) break;
+                SEC(10);  // release apply
                 const OrlgPhySvc sv = grec[victim];
                 const OrlgPathRec *rec = tb.recs + sv.gid;
                 const int pair = tb.path_pair[sv.gid];
@@ -1293,6 +1327,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
 
         if (p.mode == ORLG_MODE_STEP && p.defrag_period > 0) {
+        SEC(11);  // defragmentation
             // periodic defragmentation (phy_rmsa_env.py:355-417): services_processed % defrag_period == 0
             wave_sync();
             const long long processed = ws->c[0];
@@ -1318,6 +1353,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
     }
 
+    SEC(13);  // state store
     // ------------------------------------------------------------------ LDS -> HBM
     wave_sync();
     {
@@ -1344,5 +1380,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
     }
     wave_sync();
+    SEC(0);
     }  // work queue
+    SEC_FLUSH;
 }

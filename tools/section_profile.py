@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=0, help="env steps per launch (0 = all in one launch)")
+    ap.add_argument("--phy", default=None, help="profile the PhyRMSA kernel with this policy (bmfa, sapff, ...) instead")
+    ap.add_argument("--defrag", action="store_true")
     args = ap.parse_args()
     src = os.path.join(PKG, "csrc", "orlg_api.hip")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -25,6 +27,28 @@ def main():
         sys.path.insert(0, p)
     from conftest import load_topology
     from optical_rl_gym_amd import BatchedRMSAEnv, _lib
+    if args.phy:
+        from conftest import load_phy_tables
+        from optical_rl_gym_amd import BatchedPhyRMSAEnv
+        pairs, mod, gsnr = load_phy_tables("us14_k3")
+        env = BatchedPhyRMSAEnv(load_topology("us14_3-paths_6-modulations"), args.batch, modulation_level=mod, connections_detail=pairs,
+                                gsnr=gsnr, load=1400, mean_service_holding_time=25, episode_length=200, seed=10,
+                                defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None)
+        names = ["idle/ticket", "state load", "policy: virtual layer", "policy: row metrics", "policy: channel selection", "provision",
+                 "outputs", "next arrival + RNG", "", "release: buffer / rebuild", "release apply (+ next scan)", "defragmentation", "",
+                 "state store", "", ""]
+        env.run(args.phy, 3000, auto_reset=True)
+        L = _lib.load()
+        out = (C.c_ulonglong * 16)()
+        L.orlg_debug_sections(out, 1)
+        env.run(args.phy, args.steps, auto_reset=True)
+        env.synchronize()
+        L.orlg_debug_sections(out, 1)
+        tot = sum(out)
+        res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(14) if names[i]}
+        res["cycles_per_env_step"] = tot / (args.batch * args.steps)
+        print(json.dumps({"kernel": "phy", "policy": args.phy, "defrag": args.defrag, "percent_of_wave_cycles": res}))
+        return
     env = BatchedRMSAEnv(load_topology("nsfnet_chen_5-paths_6-modulations"), args.batch, num_spectrum_resources=320, load=50,
                          mean_service_holding_time=25, episode_length=1000, seed=10, stats_level=args.stats)
     env.run("sap_ff", 500, auto_reset=True)
