@@ -469,6 +469,12 @@ DEV int wave_max_i32(int v) {
     o = dpp_bcast31(v); v = o > v ? o : v;
     return __builtin_amdgcn_readlane(v, 63);
 }
+DEV int wave_add_i32(int v) {
+    v += dpp_xor1(v); v += dpp_xor2(v); v += dpp_half_mirror(v); v += dpp_row_mirror(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 #define ORLG_DPP_F64(fn, x) __hiloint2double(fn(__double2hiint(x)), fn(__double2loint(x)))
 DEV double wave_max_f64(double v) {
     double o = ORLG_DPP_F64(dpp_xor1, v); v = o > v ? o : v;

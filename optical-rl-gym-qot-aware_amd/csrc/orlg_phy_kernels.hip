@@ -185,8 +185,7 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
             runs = __builtin_popcount(col & ~(col << 1));
             if (want_rss) scratch_d[ch] = ch < C ? rss_of_column(col, sqrt_tab) : 0.0;
             if (ch >= C) runs = 0;
-            for (int off = 32; off > 0; off >>= 1) runs += __shfl_xor(runs, off);
-            total_runs += runs;
+            total_runs += wave_add_i32(runs);
             continue;
         }
         for (int l = 0; l < E; ++l) {
@@ -489,12 +488,11 @@ DEV double lane_rss_delta(const u64 *occ, const double *sqrt_tab, const OrlgPath
     return ORLG_FDIV(sqrt_tab[sq1], (double)(sm1 + 1)) - ORLG_FDIV(sqrt_tab[sq0], (double)(sm0 + 1));
 }
 
-DEV u64 wave_min_u64(u64 v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const u64 o = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, off);
-        v = o < v ? o : v;
-    }
-    return v;
+// smallest of the lanes' 32-bit keys (exact as doubles); lanes without a key pass has = false; returns -1.0 when no lane has one
+DEV double wave_min_key(uint32_t key, bool has) {
+    const double none = 1e18;
+    const double m = -wave_max_f64(has ? -(double)key : -none);
+    return m >= none ? -1.0 : m;
 }
 
 // The periodic defragmentation of PhyRMSAEnv.step (phy_rmsa_env.py:355-417), run when services_processed is a multiple of
@@ -578,15 +576,16 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         long long cursor = -1;
         bool stop = p.number_moves == 0;  // the reference returns at its first check
         for (int visit = 0; visit < 2 * p.cand_cap && !stop; ++visit) {  // every visit moves the cursor up the list
-            u64 bk = ~0ull;
+            uint32_t bs = 0u;
+            int bi = -1;
             for (int c = lane; c < n_el; c += 64) {
                 const uint32_t sq = cand[c].seq;
-                if ((long long)sq > cursor) { const u64 k = ((u64)sq << 32) | cand[c].idx; bk = k < bk ? k : bk; }
+                if ((long long)sq > cursor && (bi < 0 || sq < bs)) { bs = sq; bi = (int)cand[c].idx; }
             }
-            bk = wave_min_u64(bk);
-            if (bk == ~0ull) break;
-            const int idx = (int)(uint32_t)bk;
-            const uint32_t seq0 = (uint32_t)(bk >> 32);
+            const double kmin = wave_min_key(bs, bi >= 0);
+            if (kmin < 0.0) break;
+            const uint32_t seq0 = (uint32_t)kmin;
+            const int idx = __builtin_amdgcn_readlane(bi, ctz64(ballot(bi >= 0 && bs == seq0)));
             const OrlgPhySvc *r = grec + idx;
             const int gid = uni((int)r->gid), nch = uni((int)r->nch), flags = uni((int)r->flags);
             if (lane < ORLG_PHY_MAX_CH) lch[lane] = lane < nch ? (int)r->ch[lane] : 0xffff;
@@ -629,13 +628,16 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 if (lane < nch) grec[idx].ch[lane] = (uint16_t)lch[lane];
                 if (lane == 0) grec[idx].seq = (uint32_t)ns;
                 // the list iterator skips the service that followed this one (it slid into its place)
-                u64 smin = ~0ull;
+                uint32_t sm = 0u;
+                bool hs = false;
                 for (int i = lane; i < n_running; i += 64) {
                     const uint32_t sq = grec[i].seq;
-                    if (sq > seq0) smin = (u64)sq < smin ? (u64)sq : smin;
+                    if (sq > seq0 && (!hs || sq < sm)) { sm = sq; hs = true; }
                 }
-                smin = wave_min_u64(smin);
-                cursor = (long long)smin;
+                {
+                    const double nk = wave_min_key(sm, hs);   // this service itself carries a later key: never "none"
+                    cursor = nk < 0.0 ? (long long)seq0 : (long long)nk;
+                }
                 if (n_el < p.cand_cap) {
                     if (lane == 0) { cand[n_el].seq = (uint32_t)ns; cand[n_el].idx = (uint16_t)idx; }
                     n_el += 1;
@@ -667,8 +669,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
             const uint32_t my_seq = r->seq;
             const double my_arrival = r->arrival;
             int maxn = my_n;
-            for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(maxn, off); maxn = o > maxn ? o : maxn; }
-            maxn = uni(maxn);
+            maxn = wave_max_i32(maxn);
             for (int j = 0; j < maxn; ++j) {
                 bool is_c = false;
                 double diff = 0.0;
@@ -706,11 +707,18 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const u64 o = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
                 if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = c; }
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const double od = __shfl_xor(bd, off), oa = __shfl_xor(ba, off);
-                const u64 oo = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(bo >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)bo, off);
-                const int oc = __shfl_xor(bc, off);
-                if (od > bd || (od == bd && (oa > ba || (oa == ba && oo < bo)))) { bd = od; ba = oa; bo = oo; bc = oc; }
+            // lexicographic maximum over the lanes' bests: greatest diff, then greatest age, then lowest order key (36 bits: exact
+            // as a double); the lane that holds it hands out the candidate index
+            {
+                const double ninf = -__longlong_as_double((long long)ORLG_INF_BITS);
+                const double D = wave_max_f64(bc >= 0 ? bd : ninf);
+                if (!(D > 0.0)) { bc = -1; }
+                else {
+                    const double A = wave_max_f64((bc >= 0 && bd == D) ? ba : ninf);
+                    const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
+                    const u64 wm = ballot(bc >= 0 && bd == D && ba == A && (double)bo == O);
+                    bc = __builtin_amdgcn_readlane(bc, ctz64(wm));
+                }
             }
             bc = uni(bc);
             if (bc < 0) break;
@@ -914,9 +922,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     for (int idp = 0; idp < K && !served; ++idp) {
                         const CsList l = cs_load(gcs, gcs_n, (req_src * N + req_dst) * K + idp, lane, p.cs_len);
                         int fr = lane < l.n ? cs_free(l.e) : 0;
-                        int sum = fr;
-                        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-                        sum = uni(sum);
+                        const int sum = wave_add_i32(fr);
                         if (sum * 100 >= unassigned) {
                             for (int i = 0; i < l.n && nsel < ORLG_PHY_MAX_CH; ++i) {
                                 const uint32_t en = cs_get(l, i);
