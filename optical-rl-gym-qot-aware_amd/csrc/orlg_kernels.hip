@@ -455,25 +455,25 @@ DEV int group8_max(int v) {
     o = dpp_half_mirror(v); return o > v ? o : v;
 }
 
-// whole-wave maxima with DPP (no LDS crossbar round trips): quad, half row, row, then the two row broadcasts of gfx9 leave the
-// result in lane 63
+// whole-wave reductions without LDS crossbar round trips: full-mask DPP permutations inside a row of 16 lanes (quad, half row,
+// row: every lane of a row ends with the row's result), then the four row results are read with v_readlane and combined as
+// wave-uniform values.  (The row-broadcast DPP modes with a partial row mask are avoided on purpose: whether the masked-off
+// lanes keep the right value depends on how the compiler folds the move into the ALU op.)
 DEV int dpp_row_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); }
-DEV int dpp_bcast15(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); }   // rows 1, 3 <- lane 15 of the row before
-DEV int dpp_bcast31(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); }   // rows 2, 3 <- lane 31
 DEV int wave_max_i32(int v) {
     int o = dpp_xor1(v); v = o > v ? o : v;
     o = dpp_xor2(v); v = o > v ? o : v;
     o = dpp_half_mirror(v); v = o > v ? o : v;
     o = dpp_row_mirror(v); v = o > v ? o : v;
-    o = dpp_bcast15(v); v = o > v ? o : v;
-    o = dpp_bcast31(v); v = o > v ? o : v;
-    return __builtin_amdgcn_readlane(v, 63);
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
 }
 DEV int wave_add_i32(int v) {
     v += dpp_xor1(v); v += dpp_xor2(v); v += dpp_half_mirror(v); v += dpp_row_mirror(v);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return __builtin_amdgcn_readlane(v, 63);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 #define ORLG_DPP_F64(fn, x) __hiloint2double(fn(__double2hiint(x)), fn(__double2loint(x)))
 DEV double wave_max_f64(double v) {
@@ -481,9 +481,9 @@ DEV double wave_max_f64(double v) {
     o = ORLG_DPP_F64(dpp_xor2, v); v = o > v ? o : v;
     o = ORLG_DPP_F64(dpp_half_mirror, v); v = o > v ? o : v;
     o = ORLG_DPP_F64(dpp_row_mirror, v); v = o > v ? o : v;
-    o = ORLG_DPP_F64(dpp_bcast15, v); v = o > v ? o : v;
-    o = ORLG_DPP_F64(dpp_bcast31, v); v = o > v ? o : v;
-    return readlane_d(v, 63);
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    const double a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
 }
 
 template <int W, bool LINKF, bool GRAPH>
