@@ -485,6 +485,11 @@ DEV double wave_max_f64(double v) {
     const double a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
     return a > b ? a : b;
 }
+DEV double wave_add_f64(double v) {   // the association order differs from a sequential sum: only for tolerance-based results
+    v += ORLG_DPP_F64(dpp_xor1, v); v += ORLG_DPP_F64(dpp_xor2, v);
+    v += ORLG_DPP_F64(dpp_half_mirror, v); v += ORLG_DPP_F64(dpp_row_mirror, v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
 
 template <int W, bool LINKF, bool GRAPH>
 DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
