@@ -444,11 +444,12 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         // 16 waves per CU wanted (4 per SIMD, the kernel's register budget); ties go to the larger workgroup
         const size_t lds_cu = 160 * 1024;
         int wpb = 0, best_waves = 0;
+        const int wave_cap = 16;
         for (int cand = ORLG_MAX_WAVES_PER_BLOCK; cand >= 1; cand >>= 1) {
             size_t blk = (size_t)p.l_shared_bytes + (size_t)cand * p.l_wave_bytes;
             if (blk > lds_cu) continue;
             int waves = (int)(lds_cu / blk) * cand;
-            if (waves > 16) waves = 16;
+            if (waves > wave_cap) waves = wave_cap;
             if (waves > best_waves) { best_waves = waves; wpb = cand; }
         }
         if (wpb == 0) {
@@ -830,6 +831,17 @@ int orlg_load_state(orlg_env *e, const void *buffer) {
 }
 }
 
+// the int32 shape / layout fields of an environment batch, in ORLG_SHAPE_FIELDS order (tools/shape_experiment.py)
+#define ORLG_SHAPE_FIELDS(X) X(N) X(E) X(S) X(K) X(NBR) X(Q) X(NW) X(lint_stride) X(tab_bytes) X(t_pair) X(t_recs) X(t_nslots) \
+    X(t_bitrates) X(t_brcum) X(t_srccum) X(t_dstcum) X(t_divs) X(t_inv) X(l_occ) X(l_qtime) X(l_qdesc) X(l_mt) X(l_lstat) X(l_hist) \
+    X(l_lint) X(l_scratch) X(l_wsc) X(l_ring) X(l_wave_bytes) X(l_shared_bytes) X(l_outs)
+extern "C" int orlg_debug_layout(const orlg_env *e, int32_t *out, int n) {
+    int i = 0;
+#define X(f) if (i < n) out[i] = e->p.f; i++;
+    ORLG_SHAPE_FIELDS(X)
+#undef X
+    return i;
+}
 #ifdef ORLG_SECTIONS
 extern "C" int orlg_debug_sections(unsigned long long *out, int reset) {
     HIP_TRY(hipDeviceSynchronize());

@@ -638,6 +638,9 @@ __device__ unsigned long long orlg_sections[16];
 template <int W, int STATS, bool STEPK>
 DEV void rmsa_body(const OrlgParams &p) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef ORLG_SHAPE_ASSUME
+    ORLG_SHAPE_ASSUME  // experiment (tools/shape_experiment.py): shape and layout fields as compile-time constants
+#endif
     stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
