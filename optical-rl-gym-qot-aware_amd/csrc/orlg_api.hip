@@ -7,12 +7,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/orlg.h"
 #include "orlg_kernels.hip"
+#include "orlg_group_kernels.hip"
 
 // ---------------------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
@@ -41,6 +43,10 @@ struct orlg_env {
     size_t lds_block_bytes;
     int waves_per_block;
     int resident_blocks;   // workgroups of the step kernel the device keeps resident (grid size of the work queue)
+    // four-environments-per-wave step kernel: workgroup shape, LDS bytes, resident workgroups; group_mode: -1 = not usable for
+    // this shape, 0 = off, 1 = on (first-fit policies and external actions in step mode)
+    int group_mode, group_wpb, group_resident_blocks;
+    size_t group_lds_bytes;
     int num_cu;
     uint32_t ticket_base;
     int num_paths;
@@ -191,6 +197,26 @@ static rmsa_kernel_t pick_rmsa(int W, int stats, bool step = true) {
         default: return nullptr;
     }
 }
+template <int W>
+static rmsa_kernel_t pick_group_stats(int stats) {
+    switch (stats) {
+        case 0: return orlg_rmsa_group_kernel<W, 0>;
+        case 1: return orlg_rmsa_group_kernel<W, 1>;
+        default: return orlg_rmsa_group_kernel<W, 2>;
+    }
+}
+static rmsa_kernel_t pick_group(int W, int stats) {
+    switch (W) {
+        case 1: return pick_group_stats<1>(stats);
+        case 2: return pick_group_stats<2>(stats);
+        case 3: return pick_group_stats<3>(stats);
+        case 4: return pick_group_stats<4>(stats);
+        case 5: return pick_group_stats<5>(stats);
+        case 6: return pick_group_stats<6>(stats);
+        case 8: return pick_group_stats<8>(stats);
+        default: return nullptr;
+    }
+}
 static rmsa_kernel_t pick_obs(int W) {
     switch (W) {
         case 1: return orlg_deeprmsa_obs_kernel<1>;
@@ -217,7 +243,34 @@ static masks_kernel_t pick_masks(int W) {
     }
 }
 
+// the step kernel with four environments per wave: first-fit policies and external (path, slot) actions
+static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
+    rmsa_kernel_t k = pick_group(e->W, p.stats_level);
+    if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->group_lds_bytes));
+    const int wpb = e->group_wpb;
+    if (e->group_resident_blocks <= 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->group_lds_bytes));
+        e->group_resident_blocks = (nb > 0 ? nb : 1) * e->num_cu;
+    }
+    const int n_quads = (p.B + 3) / 4;
+    int nblocks = (n_quads + wpb - 1) / wpb;
+    if (nblocks > e->group_resident_blocks) nblocks = e->group_resident_blocks;
+    OrlgParams q = p;
+    q.ticket_base = e->ticket_base;
+    q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
+    if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads;  // one draw per quad of environments a wave takes on
+    dim3 grid(nblocks), block(ORLG_WAVE * wpb);
+    hipLaunchKernelGGL(k, grid, block, e->group_lds_bytes, e->stream, q);
+    HIP_TRY(hipGetLastError());
+    return ORLG_OK;
+}
+
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
+    if (e->group_mode > 0 && p.mode == ORLG_MODE_STEP &&
+        (p.policy == ORLG_POLICY_EXT || p.policy == ORLG_POLICY_SP || p.policy == ORLG_POLICY_SAP))
+        return launch_rmsa_group(e, p);
     rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -459,6 +512,27 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         }
         e->waves_per_block = wpb;
         e->lds_block_bytes = (size_t)p.l_shared_bytes + (size_t)wpb * p.l_wave_bytes;
+    }
+    // the four-environments-per-wave kernel: one environment's LDS region (no MT19937 state, no arrival ring, scalars in
+    // registers), four per wave + the wave's MT19937 staging buffer; as many waves per workgroup as the LDS holds
+    {
+        int go = 0;
+        p.g_occ = go; go = up16(go + p.NW * 8);
+        p.g_qtime = go; go = up16(go + Q * 8);
+        p.g_qdesc = go; go = up16(go + Q * 4);
+        p.g_lstat = go; if (c->stats_level >= ORLG_STATS_FULL) go = up16(go + 4 * E * 8);
+        p.g_hist = go; go = up16(go + 4 * NBR * 4);
+        p.g_lint = go; go = up16(go + p.lint_stride * 4);
+        p.g_env_bytes = go;
+        p.g_mt = 4 * go;
+        p.g_wave_bytes = 4 * go + up16(ORLG_MT_N * 4);
+        e->group_wpb = 0;
+        for (int cand = ORLG_MAX_WAVES_PER_BLOCK; cand >= 1 && !e->group_wpb; cand--)
+            if ((size_t)p.l_shared_bytes + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
+        e->group_lds_bytes = (size_t)p.l_shared_bytes + (size_t)e->group_wpb * p.g_wave_bytes;
+        e->group_resident_blocks = 0;
+        const char *gm = getenv("ORLG_GROUP_KERNEL");
+        e->group_mode = e->group_wpb < 1 ? -1 : (gm && gm[0] == '1' ? 1 : 0);
     }
     // per-env state
     TRY(dev_alloc(e, &p.occ, (size_t)batch * p.NW));

@@ -1,0 +1,563 @@
+// orlg_group_kernels.hip -- RMSA step kernel, FOUR ENVIRONMENTS PER WAVEFRONT (one 16-lane DPP row each).
+//
+// The wave-per-environment kernel (orlg_kernels.hip) is bound by instruction issue, and most of its instructions are
+// wave-uniform control work done for one environment.  Here a wave steps four environments in lockstep: every scalar of an
+// environment (clock, pending request, counters, running sums) lives in VGPRs replicated over its row, so one instruction does
+// that piece of bookkeeping for four environments, and the bitmap work maps onto the 16 lanes of a row:
+//     (path, word) lanes   16 / W candidate paths per pass: AND of the link bitmaps; the first fit is found with a shift-and-AND
+//                          doubling over the path's W words (the next word arrives by DPP row_shl:1), then one row minimum
+//     (hop, word) lanes    provision / release of a slot window, 16 / W hops per pass
+//     queue lanes          slot j * 16 + lane: lane-local minimum, then a row minimum of (time, slot)
+//     (link, word) lanes   link statistics: 16 / W links per row and pass, reductions over a link's W lanes with DPP row_shl
+// The rows diverge (accepted / blocked, number of releases, hops): every loop runs to the longest row and predicates the others.
+// Reductions stay inside a row (full-mask DPP: quad_perm, row_half_mirror, row_mirror, row_shl), row-level votes come from
+// one ballot shifted to the row's 16 bits.  The state format in HBM is the wave-per-environment kernel's: either kernel
+// can continue a batch the other one stepped, and the reset kernel is shared.  The MT19937 state and the ring of pre-generated
+// arrivals stay in HBM: a row reads its next arrival one step ahead, and a refill (every ~62 steps per environment) is done
+// by the whole wave for one environment at a time through a per-wave LDS staging buffer (refill_requests, unchanged).
+//
+// Policies: the first-fit family (shortest path / shortest available path) and external (path, slot) actions.  Everything
+// else runs on the wave-per-environment kernel.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
+#pragma once
+#include "orlg_kernels.hip"
+
+#define ORLG_GL 16  // lanes per environment (one DPP row)
+#define ORLG_GE 4   // environments per wave
+
+DEV int row_add_i32(int v) { v += dpp_xor1(v); v += dpp_xor2(v); v += dpp_half_mirror(v); v += dpp_row_mirror(v); return v; }
+DEV int row_min_i32(int v) {
+    int o = dpp_xor1(v); v = o < v ? o : v;
+    o = dpp_xor2(v); v = o < v ? o : v;
+    o = dpp_half_mirror(v); v = o < v ? o : v;
+    o = dpp_row_mirror(v); return o < v ? o : v;
+}
+// the value of the next lane of the row (0 past the row's end): DPP row_shl:1
+DEV int dpp_row_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
+DEV u64 row_next_u64(u64 v) {
+    const uint32_t lo = (uint32_t)dpp_row_next((int)(uint32_t)v), hi = (uint32_t)dpp_row_next((int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+// votes of the lane's own row (16 bits)
+DEV uint32_t row_ballot(bool p, int lane) { return (uint32_t)(ballot(p) >> (lane & 48)) & 0xffffu; }
+// row minimum of (time, slot), ties to the lower slot: the minimum time first, then the lowest slot among the lanes that hold it
+DEV void row_min_time_slot(double &t, int &q) {
+    double m = t, o;
+    o = ORLG_DPP_F64(dpp_xor1, m); m = o < m ? o : m;
+    o = ORLG_DPP_F64(dpp_xor2, m); m = o < m ? o : m;
+    o = ORLG_DPP_F64(dpp_half_mirror, m); m = o < m ? o : m;
+    o = ORLG_DPP_F64(dpp_row_mirror, m); m = o < m ? o : m;
+    q = row_min_i32(t == m ? q : 0x7fffffff);
+    t = m;
+}
+
+// Bits b of word w such that slots [64 w + b, 64 w + b + n) are all free, for a bitmap whose W words sit on W consecutive lanes
+// of a row (w = the lane's word; `x` = 0 on lanes that hold nothing).  r_m = AND of x >> 0 .. x >> (m - 1) is doubled:
+// r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 32 so that a shift needs the next word only.  n may differ between the rows (and
+// between the paths inside a row): the loop runs to the longest, finished lanes stand still.
+template <int W>
+DEV u64 run_starts(u64 x, int n, int w) {
+    u64 r = x;
+    int have = 1;
+    for (;;) {
+        int k = n - have;
+        k = k < have ? k : have;
+        k = k < 32 ? k : 32;
+        if (ballot(k > 0) == 0ull) break;
+        u64 nxt = row_next_u64(r);
+        if (w == W - 1) nxt = 0ull;  // nothing beyond the last word
+        const int kk = k > 0 ? k : 1;
+        const u64 sh = (r >> kk) | (nxt << (64 - kk));
+        if (k > 0) { r &= sh; have += k; }
+    }
+    return r;
+}
+
+// Reductions over the W consecutive lanes that hold one link's words (W is not a power of two in general: 16 / W links share a
+// row): lane i combines lanes i .. i + W - 1 of its row with DPP row_shl:k, so the link's FIRST lane ends with the link's
+// result (the other lanes hold partial results nobody reads).  A source past the row's end leaves the identity in place.
+template <int K>
+DEV int dpp_row_shl(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x100 + K, 0xf, 0xf, false); }
+#define ORLG_SEG_REDUCE(name, IDENT, OP)                                                   \
+    template <int W>                                                                       \
+    DEV int name(int v) {                                                                  \
+        int a = v, o;                                                                      \
+        if (W > 1) { o = dpp_row_shl<1>(IDENT, v); a = OP; }                               \
+        if (W > 2) { o = dpp_row_shl<2>(IDENT, v); a = OP; }                               \
+        if (W > 3) { o = dpp_row_shl<3>(IDENT, v); a = OP; }                               \
+        if (W > 4) { o = dpp_row_shl<4>(IDENT, v); a = OP; }                               \
+        if (W > 5) { o = dpp_row_shl<5>(IDENT, v); a = OP; }                               \
+        if (W > 6) { o = dpp_row_shl<6>(IDENT, v); a = OP; }                               \
+        if (W > 7) { o = dpp_row_shl<7>(IDENT, v); a = OP; }                               \
+        return a;                                                                          \
+    }
+ORLG_SEG_REDUCE(seg_add, 0, a + o)
+ORLG_SEG_REDUCE(seg_min, 0x7fffffff, (o < a ? o : a))
+ORLG_SEG_REDUCE(seg_max, 0, (o > a ? o : a))
+#undef ORLG_SEG_REDUCE
+
+// link statistics of up to ORLG_MAX_HOPS links per row: link_stats_update (orlg_kernels.hip) with 16 / W links per row and
+// pass, one word per lane; nlinks = 0 for a row that does not take part.  links: the row's link indices (bytes, LDS).
+template <int W, bool LINKF, bool GRAPH>
+DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint8_t *links,
+                          int nlinks, double now, int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr,
+                          double &g_thr, double &g_comp, double &g_lu) {
+    static_assert(W <= 8, "at least two links per row");
+    constexpr int NS = ORLG_GL / W;  // links per row and pass
+    const int gl = lane & 15;
+    const int sl = gl / W, w = gl - sl * W;
+    double ynow = 0.0;
+    if ((LINKF || GRAPH) && nlinks > 0 && now > 0) ynow = recip_refine(now);
+    for (int h0 = 0;; h0 += NS) {
+        if (ballot(h0 < nlinks) == 0ull) break;
+        const int h = h0 + sl;
+        const bool on = sl < NS && h < nlinks;
+        int link = 0, packed = 0, lo = 0x7fff, hi = 0, ml = 0;
+        if (on) link = (int)links[h];
+        if (on) {
+            const u64 *row = occ + __mul24(link, W);
+            u64 x = row[w];
+            u64 prev = w > 0 ? row[w - 1] : 0ull;
+            u64 u = ~x & valid_mask(S, w);
+            u64 carry_f = w > 0 ? (prev >> 63) : 0ull;
+            u64 carry_u = w > 0 ? ((~prev) >> 63) : 0ull;
+            u64 fstarts = x & ~((x << 1) | carry_f);
+            u64 ustarts = u & ~((u << 1) | carry_u);
+            packed = popc64(x) | (popc64(fstarts) << 10) | (popc64(ustarts) << 20);  // free slots, free runs, used runs
+            lo = u ? 64 * w + ctz64(u) : 0x7fff;
+            hi = u ? 64 * w + 64 - clz64(u) : 0;
+            if (LINKF) {
+                int e = 0;
+                if ((x >> 63) && w < W - 1) {
+                    for (int w2 = w + 1; w2 < W; ++w2) {
+                        u64 y = row[w2];
+                        if (y == ~0ull) { e += 64; } else { e += ctz64(~y); break; }
+                    }
+                }
+                u64 st = fstarts;
+                while (st) {
+                    int b = ctz64(st);
+                    st &= st - 1;
+                    int len = free_run_length((~x) >> b, 64 - b + e);
+                    ml = len > ml ? len : ml;
+                }
+            }
+        }
+        packed = seg_add<W>(packed);
+        const int lmin = seg_min<W>(lo), lmax = seg_max<W>(hi);
+        if (LINKF) ml = seg_max<W>(ml);
+        const int freec = packed & 0x3ff, F = (packed >> 10) & 0x3ff, U = packed >> 20;
+        const bool link_lane = on && w == 0;  // one lane per link carries on
+        int dspan = 0, dgaps = 0;
+        if (link_lane) {
+            int nspan = U > 1 ? lmax - lmin : 0, ngaps = U > 1 ? U - 1 : 0;
+            int old = lint[link];
+            lint[link] = nspan | (ngaps << 16);
+            dspan = nspan - (old & 0xffff);
+            dgaps = ngaps - (old >> 16);
+        }
+        sum_span += row_add_i32(dspan);
+        sum_gaps += row_add_i32(dgaps);
+        if (LINKF && link_lane && now > 0) {
+            double *l_util = lst, *l_ef = lst + E, *l_c = lst + 2 * E, *l_lu = lst + 3 * E;
+            const double last_update = l_lu[link];
+            const double last0 = l_util[link], last1 = l_ef[link], last2 = l_c[link];
+            const u64 *row = occ + link * W;
+            const bool first_free = row[0] & 1ull;
+            const bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
+            const double cur0 = tb.div_s[S - freec];  // (S - free) / S
+            double cur1 = 0.0, cur2 = 0.0;
+            if (freec > 0) {
+                int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
+                cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
+                cur2 = U > 1 ? ORLG_FDIV((double)(lmax - lmin), (double)(S - freec)) * tb.inv_k[U] : 1.0;
+            }
+            const double time_diff = now - last_update;
+            l_util[link] = div_by((last0 * last_update) + (cur0 * time_diff), now, ynow);
+            l_ef[link] = div_by((last1 * last_update) + (cur1 * time_diff), now, ynow);
+            l_c[link] = div_by((last2 * last_update) + (cur2 * time_diff), now, ynow);
+        }
+        if (LINKF && link_lane) lst[3 * E + link] = now;
+        wave_sync();
+    }
+    if (GRAPH && nlinks > 0) {
+        // _update_network_stats (rmsa_env.py:537-560), on every lane of the row
+        comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
+        if (now > 0) {
+            const double time_diff = now - g_lu;
+            g_thr = div_by((g_thr * g_lu) + (cur_thr * time_diff), now, ynow);
+            g_comp = div_by((g_comp * g_lu) + (comp_cur * time_diff), now, ynow);
+        }
+        g_lu = now;
+    }
+}
+
+// set (release) or clear (provision) the window [s, s+n) on every link of a row's path; hops = 0: the row does not take part
+template <int W>
+DEV void group_apply_window(int lane, u64 *occ, const uint8_t *links, int hops, int s, int n, bool set_free) {
+    constexpr int HPP = ORLG_GL / W;  // hops per pass
+    const int gl = lane & 15;
+    const int hs = gl / W, w = gl - hs * W;
+    const u64 m = window_mask(s, n, w);
+    for (int h0 = 0;; h0 += HPP) {
+        if (ballot(h0 < hops) == 0ull) break;
+        const int h = h0 + hs;
+        if (hs < HPP && h < hops && m) {
+            u64 *word = occ + __mul24((int)links[h], W) + w;
+            *word = set_free ? (*word | m) : (*word & ~m);
+        }
+    }
+    wave_sync();
+}
+
+// rows copy their environment's arrays between HBM and LDS: 16 lanes x 16 bytes per instruction and row
+DEV void row_copy16(void *dst, const void *src, int bytes, int gl) {
+    const int n16 = bytes >> 4;
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (int i = gl; i < n16; i += ORLG_GL) d16[i] = s16[i];
+}
+DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
+    for (int i = gl; i < n; i += ORLG_GL) dst[i] = src[i];
+}
+
+template <int W, int STATS>
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_rmsa_group_kernel(const OrlgParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    stage_tables(smem, p);
+    const int lane = threadIdx.x & 63;
+    const int wib = uni((int)(threadIdx.x >> 6));
+    const int g = lane >> 4, gl = lane & 15;
+    const Tab tb = make_tab(smem, p);
+    unsigned char *wbase = smem + p.l_shared_bytes + (size_t)wib * p.g_wave_bytes;
+    uint32_t *mt_lds = reinterpret_cast<uint32_t *>(wbase + p.g_mt);
+    unsigned char *eb = wbase + g * p.g_env_bytes;  // this row's environment
+    u64 *occ = reinterpret_cast<u64 *>(eb + p.g_occ);
+    double *qtime = reinterpret_cast<double *>(eb + p.g_qtime);
+    uint32_t *qdesc = reinterpret_cast<uint32_t *>(eb + p.g_qdesc);
+    double *lst = reinterpret_cast<double *>(eb + p.g_lstat);
+    int32_t *hist = reinterpret_cast<int32_t *>(eb + p.g_hist);
+    int32_t *lint = reinterpret_cast<int32_t *>(eb + p.g_lint);
+
+    const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
+    constexpr bool NET = STATS >= 1;
+    constexpr bool FULL = STATS >= 2;
+    const double INF = __longlong_as_double((long long)ORLG_INF_BITS);
+    SEC_DECL
+
+    // ------------------------------------------------------------------ work queue over quads of environments
+    // quad q = environments 4q .. 4q+3; the first quad of a wave is its own index, the rest come from the ticket counter
+    // (long launches) or by striding (short ones), as in the wave-per-environment kernel
+    const int n_quads = (p.B + ORLG_GE - 1) / ORLG_GE;
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const int n_static = n_waves < n_quads ? n_waves : n_quads;
+    int quad = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+    if (quad >= n_quads) return;
+    uint32_t nxt_tk = 0;
+    for (bool first = true;; first = false) {
+    if (!first) {
+        if (p.ticket_stride) {
+            quad += n_waves;
+            if (quad >= n_quads) break;
+        } else {
+            const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_tk) - p.ticket_base;
+            if (tk >= (uint32_t)(n_quads - n_static)) break;
+            quad = n_static + (int)tk;
+        }
+    }
+    SEC(1);  // state load
+    if (!p.ticket_stride && lane == 0) nxt_tk = atomicAdd(p.ticket, 1u);
+    const int env_raw = quad * ORLG_GE + g;
+    const bool act = env_raw < p.B;          // rows past the batch's end idle (they load the last environment and store nothing)
+    const int env = act ? env_raw : p.B - 1;
+
+    // ------------------------------------------------------------------ HBM -> LDS
+    row_copy8(occ, p.occ + (size_t)env * NW, NW, gl);
+    row_copy16(qtime, p.qtime + (size_t)env * Q, Q * 8, gl);
+    row_copy16(qdesc, p.qdesc + (size_t)env * Q, Q * 4, gl);
+    if (FULL) row_copy16(lst, p.lstat + (size_t)env * 4 * E, 4 * E * 8, gl);
+    row_copy16(hist, p.hist + (size_t)env * 4 * NBR, 4 * NBR * 4, gl);
+    if (NET) row_copy16(lint, p.lint + (size_t)env * p.lint_stride, p.lint_stride * 4, gl);
+    const OrlgEnvScalars *gs = p.scal + env;
+    double current_time = gs->current_time, req_arrival = gs->req_arrival, req_holding = gs->req_holding;
+    double g_thr = gs->g_throughput, g_comp = gs->g_compactness, g_lu = gs->g_last_update;
+    long long cnt = gs->c[gl & 7];  // counter gl & 7 (lanes 8..15 mirror lanes 0..7)
+    long long sum_bitrate_running = gs->sum_bitrate_running, episodes_done = gs->episodes_done;
+    int sum_sh = gs->sum_slots_hops, n_running = gs->n_running;
+    int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
+    int mt_idx = gs->mt_idx, new_service = gs->new_service, q_overflow = gs->q_overflow;
+    int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
+    int sum_span = gs->sum_span, sum_gaps = gs->sum_gaps;
+    int eproc = (int)gs->c[2];
+    wave_sync();
+    double comp_cur = 1.0;
+    if (NET) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
+    // release queue: every lane keeps the earliest entry of its own slots (gl, gl + 16, ...) in registers -- an insert updates
+    // the receiving lane's, a release makes the lanes look at their slots again -- and the row the time of its earliest entry
+    double lm_t = INF;
+    int lm_q = 0x7fffffff;
+    for (int j = gl; j < Q; j += ORLG_GL) {
+        const double tq = qtime[j];
+        if (tq < lm_t) { lm_t = tq; lm_q = j; }
+    }
+    double next_rel = lm_t;
+    { int dummy = lm_q; row_min_time_slot(next_rel, dummy); }
+    const int cidx = gl & 7;
+
+    const int n_iter = p.n_steps;
+    const int policy = p.policy;
+    for (int t = 0; t < n_iter; ++t) {
+        SEC(2);  // policy
+        // the arrival this step ends with is requested now (the ring entry is known unless a refill comes first)
+        double pf_iat = 0.0, pf_ht = 0.0;
+        uint32_t pf_rq = 0;
+        const bool pf_ok = ring_cnt > 0;
+        if (pf_ok) {
+            const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+            pf_iat = p.ring_iat[ro]; pf_ht = p.ring_ht[ro]; pf_rq = p.ring_req[ro];
+        }
+        // ========================================================== policy: pick (path, slot)
+        const int base = tb.pair_base[req_src * N + req_dst];
+        int a_path = K, a_slot = S;  // rejection (rmsa_env.py:871,913)
+        if (policy == ORLG_POLICY_EXT) {
+            a_path = p.actions[2 * env];
+            a_slot = p.actions[2 * env + 1];
+        } else {
+            constexpr int PP = ORLG_GL / W;  // candidate paths per pass
+            const int kmax = policy == ORLG_POLICY_SP ? 1 : K;
+            const int ps = gl / W, w = gl - ps * W;
+            int found = 0x7fffffff;
+            for (int p0 = 0; p0 < kmax; p0 += PP) {
+                if (ballot(act && found == 0x7fffffff) == 0ull) break;
+                const int pp = p0 + ps;
+                const bool on = ps < PP && pp < kmax;
+                const u64 x = path_word<W>(occ, tb.recs, base + pp, w, on);
+                int n = 1;
+                if (on) n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + tb.recs[base + pp].se];
+                u64 r = run_starts<W>(x, n, w);
+                // start slots below S - n (exclusive: rmsa_env.py:860-871)
+                const int below = (S - n) - 64 * w;
+                r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+                const int cand = r ? (pp << 10) | (64 * w + ctz64(r)) : 0x7fffffff;
+                const int best = row_min_i32(cand);
+                if (found == 0x7fffffff) found = best;
+            }
+            if (found != 0x7fffffff) { a_path = found >> 10; a_slot = found & 1023; }
+        }
+
+        // ========================================================== RMSAEnv.step (rmsa_env.py:222-341)
+        SEC(3);  // validate + provision
+        const double prev_compact = comp_cur;
+        bool accepted = false;
+        const bool in_range = act && a_path >= 0 && a_path < K && a_slot >= 0 && a_slot < S;
+        const int gid = base + (in_range ? a_path : 0);
+        const OrlgPathRec *rec = tb.recs + gid;
+        const int hops = rec->hops;
+        const int n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + rec->se];
+        if (policy != ORLG_POLICY_EXT) {
+            accepted = in_range;  // a first-fit result is a free window by construction
+        } else {
+            // is_path_free on the chosen window: word gl of the path on lane gl
+            const bool on = in_range && gl < W;
+            const u64 x = path_word<W>(occ, tb.recs, gid, gl < W ? gl : 0, on);
+            const u64 m = on ? window_mask(a_slot, n, gl) : 0ull;
+            const uint32_t bad = row_ballot((x & m) != m, lane);
+            accepted = in_range && a_slot + n <= S && bad == 0u;
+        }
+        const int br_val = tb.bit_rates[req_br];
+        // ---- _provision_path (rmsa_env.py:462-513)
+        group_apply_window<W>(lane, occ, rec->link, accepted ? hops : 0, a_slot, n, false);
+        if (accepted) {
+            sum_sh += n * hops;
+            n_running += 1;
+            sum_bitrate_running += br_val;
+            cnt += (cidx == 1 || cidx == 3) ? 1 : ((cidx == 5 || cidx == 7) ? br_val : 0);
+            if (gl == 0) { hist[NBR + req_br] += 1; hist[3 * NBR + req_br] += 1; }
+        }
+        SEC(4);  // statistics at provision
+        if (NET)
+            group_link_stats<W, FULL, true>(lane, occ, lst, lint, tb, S, E, rec->link, accepted ? hops : 0, current_time, sum_span,
+                                            sum_gaps, comp_cur, sum_sh, (double)sum_bitrate_running, g_thr, g_comp, g_lu);
+        SEC(5);  // queue insert
+        {
+            // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
+            const double rel = req_arrival + req_holding;
+            bool placed = !accepted;
+            for (int q0 = 0; q0 < Q; q0 += ORLG_GL) {
+                if (ballot(!placed) == 0ull) break;
+                const uint32_t em = row_ballot(__double_as_longlong(qtime[q0 + gl]) == (long long)ORLG_INF_BITS, lane);
+                if (!placed && em) {
+                    const int l = __builtin_ctz(em);
+                    if (gl == l) {
+                        qtime[q0 + l] = rel;
+                        qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
+                        if (rel < lm_t || (rel == lm_t && q0 + l < lm_q)) { lm_t = rel; lm_q = q0 + l; }
+                    }
+                    placed = true;
+                }
+            }
+            if (!placed) q_overflow = 1;
+            if (accepted) next_rel = rel < next_rel ? rel : next_rel;
+            wave_sync();
+        }
+
+        SEC(6);  // outputs
+        // per-step outputs (first lane of the row)
+        if (p.out_mask && act && gl == 0) {
+            const size_t o = (size_t)t * p.B + env;
+            const int om = p.out_mask;
+            if (om & (1 << ORLG_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_PATH])[o] = a_path;
+            if (om & (1 << ORLG_OUT_SLOT)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
+            if (om & (1 << ORLG_OUT_ACCEPTED)) reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
+            if (om & (1 << ORLG_OUT_REWARD))
+                reinterpret_cast<double *>(tb.outs[ORLG_OUT_REWARD])[o] =
+                    p.reward_mode == 1 ? (accepted ? 1.0 : -1.0) : (accepted ? 1.0 : 0.0);
+            if (om & (1 << ORLG_OUT_REQUEST))
+                reinterpret_cast<int4 *>(tb.outs[ORLG_OUT_REQUEST])[o] = make_int4(req_sid, req_src, req_dst, br_val);
+            if (om & (1 << ORLG_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_ARRIVAL])[o] = req_arrival;
+            if (om & (1 << ORLG_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_HOLDING])[o] = req_holding;
+            if (om & (1 << ORLG_OUT_COMPACT)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
+            if (om & (1 << ORLG_OUT_COMPACT_DIFF))
+                reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
+            if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_COMPACT)))
+                reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(lst + 2 * E, E);
+            if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_UTIL)))
+                reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(lst, E);
+        }
+        new_service = 0;
+
+        // ============================================================== _next_service (rmsa_env.py:643-695)
+        SEC(7);  // next arrival
+        {
+            // a row whose ring ran dry: the whole wave generates the next ORLG_RING arrivals of that environment
+            bool dry = act && ring_cnt == 0;
+            for (u64 m = ballot(dry); m; m = ballot(dry)) {
+                SEC(8);  // refill
+                const int src_lane = ctz64(m) & 48;
+                const int env_s = __builtin_amdgcn_readlane(env, src_lane);
+                int idx_s = __builtin_amdgcn_readlane(mt_idx, src_lane);
+                copy_words(mt_lds, p.mt + (size_t)env_s * ORLG_MT_N, ORLG_MT_N * 4, lane);
+                wave_sync();
+                const int got = refill_requests(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
+                                                p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N,
+                                                NBR, p.arrival_lambda, p.holding_lambda);
+                copy_words(p.mt + (size_t)env_s * ORLG_MT_N, mt_lds, ORLG_MT_N * 4, lane);
+                __threadfence();  // the ring entries written by other lanes are read back through the vector cache below
+                wave_sync();
+                if ((lane & 48) == src_lane) { ring_cnt = got; ring_pos = 0; mt_idx = idx_s; dry = false; }
+            }
+            SEC(7);
+            double r_iat = pf_iat, r_ht = pf_ht;
+            uint32_t rq = pf_rq;
+            if (!pf_ok) {
+                const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+                r_iat = p.ring_iat[ro]; r_ht = p.ring_ht[ro]; rq = p.ring_req[ro];
+            }
+            if (act) {
+                const double at = current_time + r_iat;
+                ring_pos += 1; ring_cnt -= 1;
+                current_time = at;
+                req_src = (int)(rq & 0xffu); req_dst = (int)((rq >> 8) & 0xffu); req_br = (int)(rq >> 16);
+                req_sid = eproc;
+                new_service = 1;
+                eproc += 1;
+                req_arrival = at; req_holding = r_ht;
+                const int bv = tb.bit_rates[req_br];
+                cnt += (cidx == 0 || cidx == 2) ? 1 : ((cidx == 4 || cidx == 6) ? bv : 0);
+                if (gl == 0) { hist[req_br] += 1; hist[2 * NBR + req_br] += 1; }
+            }
+
+            // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
+            bool released = false;
+            for (;;) {
+                SEC(9);  // release scan
+                const bool due = act && next_rel <= current_time;
+                if (ballot(due) == 0ull) break;
+                double bt = lm_t;
+                int bq = lm_q;
+                row_min_time_slot(bt, bq);
+                const bool rel_now = due && bt <= current_time;
+                if (due && !rel_now) next_rel = bt;  // the queue's earliest entry lies ahead: no scan until then
+                if (ballot(rel_now) == 0ull) break;
+                SEC(10);  // release apply
+                // ---- _release_path (rmsa_env.py:515-535)
+                uint32_t d = 0;
+                if (rel_now) d = qdesc[bq];
+                const int gid2 = (int)(d & 0x3fff), s0 = (int)((d >> 14) & 0x3ff), bri2 = (int)(d >> 24);
+                const OrlgPathRec *rec2 = tb.recs + gid2;
+                const int hops2 = rec2->hops;
+                const int n2 = tb.nslots[bri2 * ORLG_NSLOT_STRIDE + rec2->se];
+                if (rel_now) {
+                    if (gl == (bq & 15)) qtime[bq] = INF;
+                    n_running -= 1;
+                    sum_bitrate_running -= tb.bit_rates[bri2];
+                    sum_sh -= n2 * hops2;
+                    released = true;
+                }
+                group_apply_window<W>(lane, occ, rec2->link, rel_now ? hops2 : 0, s0, n2, true);
+                lm_t = INF; lm_q = 0x7fffffff;
+                for (int j = gl; j < Q; j += ORLG_GL) {
+                    const double tq = qtime[j];
+                    if (tq < lm_t) { lm_t = tq; lm_q = j; }
+                }
+                SEC(11);  // statistics at release
+                if (NET)
+                    group_link_stats<W, FULL, false>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
+                                                     sum_span, sum_gaps, comp_cur, sum_sh, 0.0, g_thr, g_comp, g_lu);
+            }
+            if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
+        }
+
+        // ============================================================== done / episode reset
+        SEC(12);
+        {
+            const bool done = act && eproc == p.episode_length;
+            if (act && gl == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
+                reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
+            if (ballot(done && p.auto_reset)) {
+                // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
+                if (done && p.auto_reset) {
+                    for (int i = gl; i < NBR; i += ORLG_GL) { hist[2 * NBR + i] = 0; hist[3 * NBR + i] = 0; }
+                    eproc = 1;
+                    episodes_done += 1;
+                    const int bv = tb.bit_rates[req_br];
+                    if (cidx == 2) cnt = 1;
+                    if (cidx == 3 || cidx == 7) cnt = 0;
+                    if (cidx == 6) cnt = bv;
+                }
+                wave_sync();
+                if (done && p.auto_reset && gl == 0) hist[2 * NBR + req_br] = 1;
+                wave_sync();
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ LDS -> HBM
+    SEC(13);  // state store
+    wave_sync();
+    if (act) {
+        row_copy8(p.occ + (size_t)env * NW, occ, NW, gl);
+        row_copy16(p.qtime + (size_t)env * Q, qtime, Q * 8, gl);
+        row_copy16(p.qdesc + (size_t)env * Q, qdesc, Q * 4, gl);
+        if (FULL) row_copy16(p.lstat + (size_t)env * 4 * E, lst, 4 * E * 8, gl);
+        row_copy16(p.hist + (size_t)env * 4 * NBR, hist, 4 * NBR * 4, gl);
+        if (NET) row_copy16(p.lint + (size_t)env * p.lint_stride, lint, p.lint_stride * 4, gl);
+        OrlgEnvScalars *go = p.scal + env;
+        if (gl < 8) go->c[gl] = cnt;
+        if (gl == 8) {
+            go->current_time = current_time;
+            go->req_arrival = req_arrival; go->req_holding = req_holding;
+            go->g_throughput = g_thr; go->g_compactness = g_comp; go->g_last_update = g_lu;
+            go->sum_bitrate_running = sum_bitrate_running;
+            go->episodes_done = episodes_done;
+            go->sum_slots_hops = sum_sh; go->n_running = n_running;
+            go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
+            go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = q_overflow;
+            go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
+            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
+        }
+    }
+    wave_sync();
+    SEC(0);
+    }  // work queue
+    SEC_FLUSH;
+}
