@@ -31,6 +31,12 @@ DEV int row_min_i32(int v) {
     o = dpp_half_mirror(v); v = o < v ? o : v;
     o = dpp_row_mirror(v); return o < v ? o : v;
 }
+// the value of the previous lane of the row (0 before the row's start): DPP row_shr:1
+DEV int dpp_row_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+DEV u64 row_prev_u64(u64 v) {
+    const uint32_t lo = (uint32_t)dpp_row_prev((int)(uint32_t)v), hi = (uint32_t)dpp_row_prev((int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
 // the value of the next lane of the row (0 past the row's end): DPP row_shl:1
 DEV int dpp_row_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
 DEV u64 row_next_u64(u64 v) {
@@ -113,10 +119,28 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         const bool on = sl < NS && h < nlinks;
         int link = 0, packed = 0, lo = 0x7fff, hi = 0, ml = 0;
         if (on) link = (int)links[h];
+        // the link's words sit on consecutive lanes: the neighbours' words arrive by DPP instead of further LDS reads
+        u64 x = 0ull;
+        if (on) x = occ[__mul24(link, W) + w];
+        const u64 prev = row_prev_u64(x);
+        int e = 0;  // free slots that continue a run reaching this word's end into the next words
+        if (LINKF) {
+            const int lead = x == ~0ull ? 64 : ctz64(~x);  // free slots at the word's start
+            // (the DPP reads stand outside any condition: a lane switched off by a branch is not a readable source)
+            const int nlead_raw = dpp_row_next(lead);
+            const int nlead = w < W - 1 ? nlead_raw : 0;
+            e = nlead;
+#pragma unroll
+            for (int i = 0; i < W - 2; ++i) {
+                const int ne_raw = dpp_row_next(e);
+                const int ne = w < W - 1 ? ne_raw : 0;
+                e = nlead == 64 ? 64 + ne : nlead;
+            }
+        }
+        const bool first_free = x & 1ull;                                                     // meaningful on w == 0
+        const int last_free_bit = (int)((x >> ((S - 1) & 63)) & 1ull);
+        const bool last_free = W == 1 ? last_free_bit != 0 : dpp_row_shl<(W > 1 ? W - 1 : 1)>(0, last_free_bit) != 0;  // slot S - 1, seen from w == 0
         if (on) {
-            const u64 *row = occ + __mul24(link, W);
-            u64 x = row[w];
-            u64 prev = w > 0 ? row[w - 1] : 0ull;
             u64 u = ~x & valid_mask(S, w);
             u64 carry_f = w > 0 ? (prev >> 63) : 0ull;
             u64 carry_u = w > 0 ? ((~prev) >> 63) : 0ull;
@@ -126,13 +150,6 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
             lo = u ? 64 * w + ctz64(u) : 0x7fff;
             hi = u ? 64 * w + 64 - clz64(u) : 0;
             if (LINKF) {
-                int e = 0;
-                if ((x >> 63) && w < W - 1) {
-                    for (int w2 = w + 1; w2 < W; ++w2) {
-                        u64 y = row[w2];
-                        if (y == ~0ull) { e += 64; } else { e += ctz64(~y); break; }
-                    }
-                }
                 u64 st = fstarts;
                 while (st) {
                     int b = ctz64(st);
@@ -161,9 +178,6 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
             double *l_util = lst, *l_ef = lst + E, *l_c = lst + 2 * E, *l_lu = lst + 3 * E;
             const double last_update = l_lu[link];
             const double last0 = l_util[link], last1 = l_ef[link], last2 = l_c[link];
-            const u64 *row = occ + link * W;
-            const bool first_free = row[0] & 1ull;
-            const bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
             const double cur0 = tb.div_s[S - freec];  // (S - free) / S
             double cur1 = 0.0, cur2 = 0.0;
             if (freec > 0) {
@@ -294,11 +308,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
     // release queue: every lane keeps the earliest entry of its own slots (gl, gl + 16, ...) in registers -- an insert updates
     // the receiving lane's, a release makes the lanes look at their slots again -- and the row the time of its earliest entry
     double lm_t = INF;
-    int lm_q = 0x7fffffff;
+    int lm_q = 0x7fffffff, q_top = 0;  // q_top: slots at or beyond it are empty (the queue fills from slot 0)
     for (int j = gl; j < Q; j += ORLG_GL) {
         const double tq = qtime[j];
         if (tq < lm_t) { lm_t = tq; lm_q = j; }
+        if (tq < INF) q_top = j + 1;
     }
+    q_top = -row_min_i32(-q_top);
     double next_rel = lm_t;
     { int dummy = lm_q; row_min_time_slot(next_rel, dummy); }
     const int cidx = gl & 7;
@@ -392,6 +408,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                         qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
                         if (rel < lm_t || (rel == lm_t && q0 + l < lm_q)) { lm_t = rel; lm_q = q0 + l; }
                     }
+                    q_top = q0 + l + 1 > q_top ? q0 + l + 1 : q_top;
                     placed = true;
                 }
             }
@@ -495,7 +512,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                 }
                 group_apply_window<W>(lane, occ, rec2->link, rel_now ? hops2 : 0, s0, n2, true);
                 lm_t = INF; lm_q = 0x7fffffff;
-                for (int j = gl; j < Q; j += ORLG_GL) {
+                for (int j = gl; j < q_top; j += ORLG_GL) {
                     const double tq = qtime[j];
                     if (tq < lm_t) { lm_t = tq; lm_q = j; }
                 }
