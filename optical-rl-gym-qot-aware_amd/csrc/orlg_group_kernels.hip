@@ -56,6 +56,25 @@ DEV void row_min_time_slot(double &t, int &q) {
     t = m;
 }
 
+// path_word (orlg_kernels.hip) that also hands back the record's spectral efficiency and hop count (0 on inactive lanes)
+template <int W>
+DEV u64 path_word_rec(const u64 *occ, const OrlgPathRec *recs, int gid, int w, bool active, int &se, int &hops_out) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (active) r = *reinterpret_cast<const uint4 *>(recs + gid);
+    const uint32_t q[4] = {r.x, r.y, r.z, r.w};
+    const int hops = (int)(r.x & 0xffu);
+    se = (int)((r.x >> 8) & 0xffu);
+    hops_out = hops;
+    u64 acc = active ? ~0ull : 0ull;
+#pragma unroll
+    for (int h = 0; h < ORLG_MAX_HOPS; ++h) {
+        if (ballot(h < hops) == 0ull) break;
+        const int link = (int)((q[(h + 2) >> 2] >> (8 * ((h + 2) & 3))) & 0xffu);
+        if (h < hops) acc &= occ[__mul24(link, W) + w];
+    }
+    return acc;
+}
+
 // Bits b of word w such that slots [64 w + b, 64 w + b + n) are all free, for a bitmap whose W words sit on W consecutive lanes
 // of a row (w = the lane's word; `x` = 0 on lanes that hold nothing).  r_m = AND of x >> 0 .. x >> (m - 1) is doubled:
 // r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 32 so that a shift needs the next word only.  n may differ between the rows (and
@@ -318,6 +337,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
     double next_rel = lm_t;
     { int dummy = lm_q; row_min_time_slot(next_rel, dummy); }
     const int cidx = gl & 7;
+    int req_base = tb.pair_base[req_src * N + req_dst];  // first path record of the pending request's node pair
 
     const int n_iter = p.n_steps;
     const int policy = p.policy;
@@ -332,8 +352,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
             pf_iat = p.ring_iat[ro]; pf_ht = p.ring_ht[ro]; pf_rq = p.ring_req[ro];
         }
         // ========================================================== policy: pick (path, slot)
-        const int base = tb.pair_base[req_src * N + req_dst];
+        const int base = req_base;
         int a_path = K, a_slot = S;  // rejection (rmsa_env.py:871,913)
+        int ff_n = 1, ff_hops = 0;
         if (policy == ORLG_POLICY_EXT) {
             a_path = p.actions[2 * env];
             a_slot = p.actions[2 * env + 1];
@@ -346,18 +367,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                 if (ballot(act && found == 0x7fffffff) == 0ull) break;
                 const int pp = p0 + ps;
                 const bool on = ps < PP && pp < kmax;
-                const u64 x = path_word<W>(occ, tb.recs, base + pp, w, on);
+                int se_pp, hops_pp;
+                const u64 x = path_word_rec<W>(occ, tb.recs, base + pp, w, on, se_pp, hops_pp);
                 int n = 1;
-                if (on) n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + tb.recs[base + pp].se];
+                if (on) n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + se_pp];
                 u64 r = run_starts<W>(x, n, w);
                 // start slots below S - n (exclusive: rmsa_env.py:860-871)
                 const int below = (S - n) - 64 * w;
                 r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
-                const int cand = r ? (pp << 10) | (64 * w + ctz64(r)) : 0x7fffffff;
+                // key: (path, start slot) decide; the path's slot count and hops ride along in the low bits
+                const int cand = r ? ((((pp << 10) | (64 * w + ctz64(r))) << 14) | (n << 4) | hops_pp) : 0x7fffffff;
                 const int best = row_min_i32(cand);
                 if (found == 0x7fffffff) found = best;
             }
-            if (found != 0x7fffffff) { a_path = found >> 10; a_slot = found & 1023; }
+            if (found != 0x7fffffff) { a_path = found >> 24; a_slot = (found >> 14) & 1023; ff_n = (found >> 4) & 1023; ff_hops = found & 15; }
         }
 
         // ========================================================== RMSAEnv.step (rmsa_env.py:222-341)
@@ -367,11 +390,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
         const bool in_range = act && a_path >= 0 && a_path < K && a_slot >= 0 && a_slot < S;
         const int gid = base + (in_range ? a_path : 0);
         const OrlgPathRec *rec = tb.recs + gid;
-        const int hops = rec->hops;
-        const int n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + rec->se];
+        int hops = ff_hops, n = ff_n;
         if (policy != ORLG_POLICY_EXT) {
             accepted = in_range;  // a first-fit result is a free window by construction
         } else {
+            hops = rec->hops;
+            n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + rec->se];
             // is_path_free on the chosen window: word gl of the path on lane gl
             const bool on = in_range && gl < W;
             const u64 x = path_word<W>(occ, tb.recs, gid, gl < W ? gl : 0, on);
@@ -474,6 +498,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                 ring_pos += 1; ring_cnt -= 1;
                 current_time = at;
                 req_src = (int)(rq & 0xffu); req_dst = (int)((rq >> 8) & 0xffu); req_br = (int)(rq >> 16);
+                req_base = tb.pair_base[req_src * N + req_dst];
                 req_sid = eproc;
                 new_service = 1;
                 eproc += 1;
