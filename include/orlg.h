@@ -59,7 +59,7 @@ typedef struct orlg_rmsa_config {
     int32_t reward_mode;      /* 0: 1/0 (optical_network_env.py:213-214); 1: +1/-1 (deeprmsa_env.py:123-124) */
     int32_t queue_capacity;   /* release-queue slots per env, multiple of 64; 0 = pick from the load */
     int32_t stats_level;      /* ORLG_STATS_* */
-    int32_t reserved;
+    int32_t step_kernel;      /* ORLG_KERNEL_*: which step kernel serves the first-fit policies and external actions */
     double arrival_lambda;    /* 1 / mean_service_inter_arrival_time (rmsa_env.py:646-648) */
     double holding_lambda;    /* 1 / mean_service_holding_time (rmsa_env.py:651) */
     double channel_width;     /* GHz per slot, 12.5 (rmsa_env.py:46,708-719) */
@@ -68,6 +68,12 @@ typedef struct orlg_rmsa_config {
     const double *src_cum;      /* [N] */
     const double *dst_cum;      /* [N*N] row s = destination table given source s */
 } orlg_rmsa_config;
+
+/* Two step kernels share one state format.  WAVE: one wavefront per environment (every policy).  GROUP: four environments
+ * per wavefront, 16 lanes each (shortest-path / shortest-available-path first fit and external (path, slot) actions; the other
+ * policies run on WAVE).  AUTO picks GROUP for those policies unless the batch fits the WAVE kernel's resident wavefronts in
+ * a launch of more than 16 steps, where WAVE's shorter per-step latency wins.  Results are identical bit for bit. */
+enum { ORLG_KERNEL_AUTO = 0, ORLG_KERNEL_WAVE = 1, ORLG_KERNEL_GROUP = 2 };
 
 enum {
     ORLG_STATS_COUNTERS = 0, /* occupancy, queue, counters, histograms only */

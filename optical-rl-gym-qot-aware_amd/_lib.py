@@ -28,10 +28,13 @@ class Topology(C.Structure):
                 ("path_links", C.c_void_p)]
 
 
+STEP_KERNELS = {"auto": 0, "wave": 1, "group": 2}   # include/orlg.h ORLG_KERNEL_*
+
+
 class RmsaConfig(C.Structure):
     _fields_ = [("num_slots", C.c_int32), ("episode_length", C.c_int32), ("num_bit_rates", C.c_int32),
                 ("j", C.c_int32), ("reward_mode", C.c_int32), ("queue_capacity", C.c_int32),
-                ("stats_level", C.c_int32), ("reserved", C.c_int32),
+                ("stats_level", C.c_int32), ("step_kernel", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double), ("channel_width", C.c_double),
                 ("bit_rates", C.c_void_p), ("bit_rate_cum", C.c_void_p), ("src_cum", C.c_void_p),
                 ("dst_cum", C.c_void_p)]

@@ -40,7 +40,8 @@ class BatchedRMSAEnv:
                  bit_rate_selection: str = "discrete", bit_rates: Sequence[int] = DEFAULT_BIT_RATES,
                  bit_rate_probabilities=None, node_request_probabilities=None, seed: Optional[int] = None,
                  seeds=None, allow_rejection: bool = False, channel_width: float = 12.5, j: int = 1,
-                 reward_mode: int = 0, stats_level: str = "full", queue_capacity: int = 0, device: int = 0):
+                 reward_mode: int = 0, stats_level: str = "full", queue_capacity: int = 0, device: int = 0,
+                 step_kernel: str = "auto"):
         if bit_rate_selection != "discrete":
             raise NotImplementedError("only bit_rate_selection='discrete' runs on the device path")
         self.L = _lib.load()
@@ -84,6 +85,7 @@ class BatchedRMSAEnv:
         cc.num_slots, cc.episode_length, cc.num_bit_rates = self.num_spectrum_resources, self.episode_length, len(self.bit_rates)
         cc.j, cc.reward_mode, cc.queue_capacity = self.j, int(reward_mode), int(queue_capacity)
         cc.stats_level = _lib.STATS_LEVELS[stats_level]
+        cc.step_kernel = _lib.STEP_KERNELS[step_kernel]
         # rmsa_env.py:646-651: expovariate(1 / mean)
         cc.arrival_lambda = 1 / self.mean_service_inter_arrival_time
         cc.holding_lambda = 1 / self.mean_service_holding_time

@@ -43,8 +43,8 @@ struct orlg_env {
     size_t lds_block_bytes;
     int waves_per_block;
     int resident_blocks;   // workgroups of the step kernel the device keeps resident (grid size of the work queue)
-    // four-environments-per-wave step kernel: workgroup shape, LDS bytes, resident workgroups; group_mode: -1 = not usable for
-    // this shape, 0 = off, 1 = on (first-fit policies and external actions in step mode)
+    // four-environments-per-wave step kernel: workgroup shape, LDS bytes, resident workgroups; group_mode = ORLG_KERNEL_*
+    // (AUTO falls back to WAVE when the shape does not fit the kernel's LDS budget)
     int group_mode, group_wpb, group_resident_blocks;
     size_t group_lds_bytes;
     int num_cu;
@@ -267,10 +267,16 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     return ORLG_OK;
 }
 
+static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
+    if (e->group_mode == ORLG_KERNEL_WAVE || p.mode != ORLG_MODE_STEP) return false;
+    if (p.policy != ORLG_POLICY_EXT && p.policy != ORLG_POLICY_SP && p.policy != ORLG_POLICY_SAP) return false;
+    if (e->group_mode == ORLG_KERNEL_GROUP) return true;
+    // AUTO: a long launch over a batch that fits the wave-per-environment kernel's resident waves is bound by the latency of
+    // one environment's step chain, which is shorter there; everything else is bound by throughput, which is higher here
+    return !(p.n_steps > 16 && p.B <= e->resident_blocks * e->waves_per_block);
+}
+
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
-    if (e->group_mode > 0 && p.mode == ORLG_MODE_STEP &&
-        (p.policy == ORLG_POLICY_EXT || p.policy == ORLG_POLICY_SP || p.policy == ORLG_POLICY_SAP))
-        return launch_rmsa_group(e, p);
     rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -283,6 +289,7 @@ static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(ks), ORLG_WAVE * wpb, e->lds_block_bytes));
         e->resident_blocks = (nb > 0 ? nb : 1) * e->num_cu;
     }
+    if (group_kernel_serves(e, p)) return launch_rmsa_group(e, p);
     int nblocks = (p.B + wpb - 1) / wpb;
     if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
     OrlgParams q = p;
@@ -531,8 +538,20 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
             if ((size_t)p.l_shared_bytes + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
         e->group_lds_bytes = (size_t)p.l_shared_bytes + (size_t)e->group_wpb * p.g_wave_bytes;
         e->group_resident_blocks = 0;
-        const char *gm = getenv("ORLG_GROUP_KERNEL");
-        e->group_mode = e->group_wpb < 1 ? -1 : (gm && gm[0] == '1' ? 1 : 0);
+        e->group_mode = c->step_kernel;
+        const char *gm = getenv("ORLG_GROUP_KERNEL");  // tooling override: 0 = WAVE, 1 = GROUP
+        if (gm && (gm[0] == '0' || gm[0] == '1')) e->group_mode = gm[0] == '1' ? ORLG_KERNEL_GROUP : ORLG_KERNEL_WAVE;
+        if (e->group_mode < ORLG_KERNEL_AUTO || e->group_mode > ORLG_KERNEL_GROUP) {
+            orlg_destroy(e);
+            return fail(ORLG_ERR_INVALID, "step_kernel %d: not one of ORLG_KERNEL_AUTO / WAVE / GROUP", c->step_kernel);
+        }
+        if (e->group_wpb < 1) {
+            if (e->group_mode == ORLG_KERNEL_GROUP) {
+                orlg_destroy(e);
+                return fail(ORLG_ERR_INVALID, "step_kernel GROUP: four environments (%d B each) do not fit the LDS", p.g_env_bytes);
+            }
+            e->group_mode = ORLG_KERNEL_WAVE;
+        }
     }
     // per-env state
     TRY(dev_alloc(e, &p.occ, (size_t)batch * p.NW));

@@ -264,11 +264,10 @@ __device__ __noinline__ int refill_requests(uint32_t *mt, double *ring_iat, doub
         const double x = u[4] * (br_cum[NBR - 1] + 0.0);
         for (int i = 0; i < NBR - 1; ++i) bri += br_cum[i] <= x ? 1 : 0;
     }
-    if (lane < n) {
-        ring_iat[lane] = iat;
-        ring_ht[lane] = ht;
-        ring_req[lane] = (uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)bri << 16);
-    }
+    // entries past n are dead; they are zeroed so that a snapshot of the state does not depend on what the ring held before
+    ring_iat[lane] = lane < n ? iat : 0.0;
+    ring_ht[lane] = lane < n ? ht : 0.0;
+    ring_req[lane] = lane < n ? ((uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)bri << 16)) : 0u;
     wave_sync();
     *idx_io = idx;
     return n;

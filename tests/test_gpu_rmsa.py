@@ -25,11 +25,26 @@ OUTS = ("act_path", "act_slot", "accepted", "done", "reward", "request", "arriva
         "network_compactness", "network_compactness_difference")
 
 
+STEP_KERNEL = "auto"
+
+
+@pytest.fixture(autouse=True, params=["wave", "group"])
+def step_kernel(request):
+    """Every test of this module runs against both step kernels (include/orlg.h ORLG_KERNEL_*): one wavefront per
+    environment, and four environments per wavefront (which serves the first-fit policies and external actions and hands
+    every other policy to the first)."""
+    global STEP_KERNEL
+    STEP_KERNEL = request.param
+    yield request.param
+    STEP_KERNEL = "auto"
+
+
 def make_batched(topo, kw, batch, **extra):
     from optical_rl_gym_amd import BatchedRMSAEnv
     kw = dict(kw)
     kw.pop("allow_rejection", None)
     kw.pop("reset", None)
+    extra.setdefault("step_kernel", STEP_KERNEL)
     return BatchedRMSAEnv(topo, batch, **kw, **extra)
 
 
@@ -284,3 +299,34 @@ def test_path_masks_query(nsfnet):
             assert want == got
     env.close()
     o.close()
+
+
+def test_kernels_continue_each_other(nsfnet):
+    """One state format: a batch stepped by the wave-per-environment kernel is handed (save_state / load_state) to the
+    four-environments-per-wave kernel and back; outputs and final state equal an uninterrupted run."""
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=150, seed=21)
+    B = 7   # not a multiple of four: the last wave of the group kernel has an idle row
+    outs = ("act_path", "act_slot", "accepted", "arrival", "network_compactness", "done")
+    ref = make_batched(nsfnet, kw, B, step_kernel="wave")
+    a = make_batched(nsfnet, kw, B, step_kernel="wave")
+    b = make_batched(nsfnet, kw, B, step_kernel="group")
+    t_ref = ref.run("sap_ff", 700, outputs=outs, auto_reset=True)
+    parts = []
+    cur, other = a, b
+    for n in (130, 1, 200, 69, 300):
+        parts.append(cur.run("sap_ff", n, outputs=outs, auto_reset=True))
+        other.load_state(cur.save_state())
+        cur, other = other, cur
+    for k in outs:
+        assert np.array_equal(t_ref[k], np.concatenate([p[k] for p in parts])), k
+    assert np.array_equal(ref.occupancy_words(), cur.occupancy_words())
+    ca, cb = ref.counters(), cur.counters()
+    for name in ca:
+        assert np.array_equal(ca[name], cb[name]), name
+    la, lb = ref.link_stats(), cur.link_stats()
+    for name in la:
+        assert np.array_equal(la[name], lb[name]), name
+    assert np.array_equal(ref.episodes_done(), cur.episodes_done())
+    assert np.array_equal(ref.save_state(), cur.save_state())   # byte for byte: queue slots, RNG state, arrival ring, caches
+    for env in (ref, a, b):
+        env.close()
