@@ -853,11 +853,16 @@ DEV void rmsa_body(const OrlgParams &p) {
             const double prev_compact = comp_cur;
             bool accepted = false;
             if (a_path >= 0 && a_path < K && a_slot >= 0 && a_slot < S) {
-                u64 x[W];
-#pragma unroll
-                for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a_path * W + w);
                 const int n = __builtin_amdgcn_readlane(my_n, a_path);
-                if (window_free<W>(x, a_slot, n, S)) {
+                // the device policies only propose windows they found free; agent actions are checked (is_path_free)
+                bool window_ok = true;
+                if (policy == ORLG_POLICY_EXT || policy == ORLG_POLICY_PATH_EXT || policy == ORLG_POLICY_DEEP_EXT) {
+                    u64 x[W];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a_path * W + w);
+                    window_ok = window_free<W>(x, a_slot, n, S);
+                }
+                if (window_ok) {
                     // ---- _provision_path (rmsa_env.py:462-513)
                     const int gid = base + a_path;
                     const OrlgPathRec *rec = tb.recs + gid;
