@@ -442,6 +442,16 @@ DEV KernargParams kernarg_params() {
 DEV int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
 DEV int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); }   // quad_perm [2,3,0,1]
 DEV int dpp_half_mirror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false); }
+// neighbours inside a row of 16 lanes: the previous lane (row_shr:1), the next lane (row_shl:1), K lanes ahead (row_shl:K);
+// 0 where the row ends
+DEV int lane_prev_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+DEV int lane_next_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
+template <int K>
+DEV int lane_ahead_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + K, 0xf, 0xf, true); }
+DEV u64 lane_prev_u64(u64 v) {
+    const uint32_t lo = (uint32_t)lane_prev_i32((int)(uint32_t)v), hi = (uint32_t)lane_prev_i32((int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
 DEV int group8_add(int v) { v += dpp_xor1(v); v += dpp_xor2(v); v += dpp_half_mirror(v); return v; }
 DEV int group8_min(int v) {
     int o = dpp_xor1(v); v = o < v ? o : v;
@@ -505,10 +515,28 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
         // ---- per (link, word) lane: the word's run statistics ...
         int link = 0, packed = 0, lo = 0x7fff, hi = 0, ml = 0;
         if (hl < nl) link = links ? (int)links[h0 + hl] : h0 + hl;
+        // the link's words sit on consecutive lanes of its group: the neighbouring words arrive by DPP, not by further LDS
+        // reads (every DPP read stands outside any condition: a lane switched off by a branch is not a readable source)
+        u64 x = 0ull;
+        if (hl < nl && w < W) x = wv.occ[__mul24(link, W) + w];
+        const u64 prev = lane_prev_u64(x);
+        int e = 0;  // free slots that continue a run reaching this word's end into the next words
+        if (LINKF) {
+            const int lead = x == ~0ull ? 64 : ctz64(~x);  // free slots at the word's start
+            const int nlead_raw = lane_next_i32(lead);
+            const int nlead = w < W - 1 ? nlead_raw : 0;
+            e = nlead;
+#pragma unroll
+            for (int i = 0; i < W - 2; ++i) {
+                const int ne_raw = lane_next_i32(e);
+                const int ne = w < W - 1 ? ne_raw : 0;
+                e = nlead == 64 ? 64 + ne : nlead;
+            }
+        }
+        const bool first_free = x & 1ull;  // meaningful on the link's first lane
+        const int last_free_bit = (int)((x >> ((S - 1) & 63)) & 1ull);
+        const bool last_free = W == 1 ? last_free_bit != 0 : lane_ahead_i32<(W > 1 ? W - 1 : 1)>(last_free_bit) != 0;  // slot S - 1
         if (hl < nl && w < W) {
-            const u64 *row = wv.occ + __mul24(link, W);
-            u64 x = row[w];
-            u64 prev = w > 0 ? row[w - 1] : 0ull;
             u64 u = ~x & valid_mask(S, w);
             u64 carry_f = w > 0 ? (prev >> 63) : 0ull;
             u64 carry_u = w > 0 ? ((~prev) >> 63) : 0ull;
@@ -518,13 +546,6 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
             lo = u ? 64 * w + ctz64(u) : 0x7fff;
             hi = u ? 64 * w + 64 - clz64(u) : 0;
             if (LINKF) {
-                int e = 0;
-                if ((x >> 63) && w < W - 1) {
-                    for (int w2 = w + 1; w2 < W; ++w2) {
-                        u64 y = row[w2];
-                        if (y == ~0ull) { e += 64; } else { e += ctz64(~y); break; }
-                    }
-                }
                 u64 st = fstarts;
                 while (st) {
                     int b = ctz64(st);
@@ -565,9 +586,6 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                 if (is_link) {
                     last_update = l_lu[link];
                     last0 = l_util[link]; last1 = l_ef[link]; last2 = l_c[link];
-                    const u64 *row = wv.occ + link * W;
-                    bool first_free = row[0] & 1ull;
-                    bool last_free = (row[(S - 1) >> 6] >> ((S - 1) & 63)) & 1ull;
                     cur0 = tb.div_s[S - freec];  // (S - free) / S
                     if (freec > 0) {
                         int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
