@@ -31,18 +31,6 @@ DEV int row_min_i32(int v) {
     o = dpp_half_mirror(v); v = o < v ? o : v;
     o = dpp_row_mirror(v); return o < v ? o : v;
 }
-// the value of the previous lane of the row (0 before the row's start): DPP row_shr:1
-DEV int dpp_row_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
-DEV u64 row_prev_u64(u64 v) {
-    const uint32_t lo = (uint32_t)dpp_row_prev((int)(uint32_t)v), hi = (uint32_t)dpp_row_prev((int)(uint32_t)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
-// the value of the next lane of the row (0 past the row's end): DPP row_shl:1
-DEV int dpp_row_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
-DEV u64 row_next_u64(u64 v) {
-    const uint32_t lo = (uint32_t)dpp_row_next((int)(uint32_t)v), hi = (uint32_t)dpp_row_next((int)(uint32_t)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
 // votes of the lane's own row (16 bits)
 DEV uint32_t row_ballot(bool p, int lane) { return (uint32_t)(ballot(p) >> (lane & 48)) & 0xffffu; }
 // row minimum of (time, slot), ties to the lower slot: the minimum time first, then the lowest slot among the lanes that hold it
@@ -54,47 +42,6 @@ DEV void row_min_time_slot(double &t, int &q) {
     o = ORLG_DPP_F64(dpp_row_mirror, m); m = o < m ? o : m;
     q = row_min_i32(t == m ? q : 0x7fffffff);
     t = m;
-}
-
-// path_word (orlg_kernels.hip) that also hands back the record's spectral efficiency and hop count (0 on inactive lanes)
-template <int W>
-DEV u64 path_word_rec(const u64 *occ, const OrlgPathRec *recs, int gid, int w, bool active, int &se, int &hops_out) {
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (active) r = *reinterpret_cast<const uint4 *>(recs + gid);
-    const uint32_t q[4] = {r.x, r.y, r.z, r.w};
-    const int hops = (int)(r.x & 0xffu);
-    se = (int)((r.x >> 8) & 0xffu);
-    hops_out = hops;
-    u64 acc = active ? ~0ull : 0ull;
-#pragma unroll
-    for (int h = 0; h < ORLG_MAX_HOPS; ++h) {
-        if (ballot(h < hops) == 0ull) break;
-        const int link = (int)((q[(h + 2) >> 2] >> (8 * ((h + 2) & 3))) & 0xffu);
-        if (h < hops) acc &= occ[__mul24(link, W) + w];
-    }
-    return acc;
-}
-
-// Bits b of word w such that slots [64 w + b, 64 w + b + n) are all free, for a bitmap whose W words sit on W consecutive lanes
-// of a row (w = the lane's word; `x` = 0 on lanes that hold nothing).  r_m = AND of x >> 0 .. x >> (m - 1) is doubled:
-// r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 32 so that a shift needs the next word only.  n may differ between the rows (and
-// between the paths inside a row): the loop runs to the longest, finished lanes stand still.
-template <int W>
-DEV u64 run_starts(u64 x, int n, int w) {
-    u64 r = x;
-    int have = 1;
-    for (;;) {
-        int k = n - have;
-        k = k < have ? k : have;
-        k = k < 32 ? k : 32;
-        if (ballot(k > 0) == 0ull) break;
-        u64 nxt = row_next_u64(r);
-        if (w == W - 1) nxt = 0ull;  // nothing beyond the last word
-        const int kk = k > 0 ? k : 1;
-        const u64 sh = (r >> kk) | (nxt << (64 - kk));
-        if (k > 0) { r &= sh; have += k; }
-    }
-    return r;
 }
 
 // Reductions over the W consecutive lanes that hold one link's words (W is not a power of two in general: 16 / W links share a
@@ -141,17 +88,17 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         // the link's words sit on consecutive lanes: the neighbours' words arrive by DPP instead of further LDS reads
         u64 x = 0ull;
         if (on) x = occ[__mul24(link, W) + w];
-        const u64 prev = row_prev_u64(x);
+        const u64 prev = lane_prev_u64(x);
         int e = 0;  // free slots that continue a run reaching this word's end into the next words
         if (LINKF) {
             const int lead = x == ~0ull ? 64 : ctz64(~x);  // free slots at the word's start
             // (the DPP reads stand outside any condition: a lane switched off by a branch is not a readable source)
-            const int nlead_raw = dpp_row_next(lead);
+            const int nlead_raw = lane_next_i32(lead);
             const int nlead = w < W - 1 ? nlead_raw : 0;
             e = nlead;
 #pragma unroll
             for (int i = 0; i < W - 2; ++i) {
-                const int ne_raw = dpp_row_next(e);
+                const int ne_raw = lane_next_i32(e);
                 const int ne = w < W - 1 ? ne_raw : 0;
                 e = nlead == 64 ? 64 + ne : nlead;
             }

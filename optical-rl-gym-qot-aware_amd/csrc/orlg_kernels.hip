@@ -500,6 +500,62 @@ DEV double wave_add_f64(double v) {   // the association order differs from a se
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
+DEV u64 lane_next_u64(u64 v) {
+    const uint32_t lo = (uint32_t)lane_next_i32((int)(uint32_t)v), hi = (uint32_t)lane_next_i32((int)(uint32_t)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+DEV int wave_min_i32(int v) {
+    int o = dpp_xor1(v); v = o < v ? o : v;
+    o = dpp_xor2(v); v = o < v ? o : v;
+    o = dpp_half_mirror(v); v = o < v ? o : v;
+    o = dpp_row_mirror(v); v = o < v ? o : v;
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
+// path_word that also hands back the record's spectral efficiency and hop count (0 on inactive lanes)
+template <int W>
+DEV u64 path_word_rec(const u64 *occ, const OrlgPathRec *recs, int gid, int w, bool active, int &se, int &hops_out) {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (active) r = *reinterpret_cast<const uint4 *>(recs + gid);
+    const uint32_t q[4] = {r.x, r.y, r.z, r.w};
+    const int hops = (int)(r.x & 0xffu);
+    se = (int)((r.x >> 8) & 0xffu);
+    hops_out = hops;
+    u64 acc = active ? ~0ull : 0ull;
+#pragma unroll
+    for (int h = 0; h < ORLG_MAX_HOPS; ++h) {
+        if (ballot(h < hops) == 0ull) break;
+        const int link = (int)((q[(h + 2) >> 2] >> (8 * ((h + 2) & 3))) & 0xffu);
+        if (h < hops) acc &= occ[__mul24(link, W) + w];
+    }
+    return acc;
+}
+
+// Bits b of word w such that slots [64 w + b, 64 w + b + n) are all free, for a bitmap whose W words sit on W consecutive lanes
+// of a row (w = the lane's word; `x` = 0 on lanes that hold nothing).  r_m = AND of x >> 0 .. x >> (m - 1) is doubled:
+// r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 32 so that a shift needs the next word only.  n may differ between the rows (and
+// between the paths inside a row): the loop runs to the longest, finished lanes stand still.
+template <int W>
+DEV u64 run_starts(u64 x, int n, int w) {
+    u64 r = x;
+    int have = 1;
+    for (;;) {
+        int k = n - have;
+        k = k < have ? k : have;
+        k = k < 32 ? k : 32;
+        if (ballot(k > 0) == 0ull) break;
+        u64 nxt = lane_next_u64(r);
+        if (w == W - 1) nxt = 0ull;  // nothing beyond the last word
+        const int kk = k > 0 ? k : 1;
+        const u64 sh = (r >> kk) | (nxt << (64 - kk));
+        if (k > 0) { r &= sh; have += k; }
+    }
+    return r;
+}
+
 template <int W, bool LINKF, bool GRAPH>
 DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
                            int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr) {
@@ -679,6 +735,7 @@ DEV void rmsa_body(const OrlgParams &p) {
     wv.ring_req = reinterpret_cast<uint32_t *>(wv.ring_ht + ORLG_RING);
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
+    const int LS = K <= 8 ? 8 : W;  // lanes from one candidate path to the next in the policy's (path, word) layout
     constexpr bool NET = STATS >= 1;
     constexpr bool FULL = STATS >= 2;
     SEC_DECL
@@ -801,10 +858,11 @@ DEV void rmsa_body(const OrlgParams &p) {
         if (STEPK) {
             // ========================================================== policy: pick (path, slot)
             const int base = tb.pair_base[req_src * N + req_dst];
-            // (path, word) lanes: AND over the links of candidate path pp
-            const int pp = lane / W, pw = lane - pp * W;
-            u64 acc = 0ull;
-            acc = path_word<W>(wv.occ, tb.recs, base + pp, pw, pp < K);
+            // (path, word) lanes: AND over the links of candidate path pp.  With k <= 8 a path takes a group of 8 lanes (two per
+            // row of 16, so that a path's words can exchange bits by DPP); otherwise the paths are packed W lanes apart
+            const int pp = LS == 8 ? lane >> 3 : lane / W, pw = lane - pp * LS;
+            int se_l, hops_l;
+            const u64 acc = path_word_rec<W>(wv.occ, tb.recs, base + pp, pw, pp < K && pw < W, se_l, hops_l);
             int my_se = 0;
             if (lane < K) my_se = tb.recs[base + lane].se;
             int my_n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + my_se];  // get_number_slots per candidate
@@ -821,7 +879,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 if (a >= 0 && a < K) {
                     u64 x[W];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a * W + w);
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a * LS + w);
                     int n = __builtin_amdgcn_readlane(my_n, a);
                     int s0 = first_fit<W>(x, n, S - n, lane);
                     if (s0 >= 0) { a_path = a; a_slot = s0; }
@@ -832,18 +890,30 @@ DEV void rmsa_body(const OrlgParams &p) {
                     int route = a / p.j, blk = a - route * p.j;
                     u64 x[W];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, route * W + w);
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, route * LS + w);
                     int n = __builtin_amdgcn_readlane(my_n, route), len;
                     int s0 = find_block<W>(x, n, blk, lane, &len);
                     if (s0 >= 0) { a_path = route; a_slot = s0; }
                 }
+            } else if (LS == 8 && (policy == ORLG_POLICY_SP || policy == ORLG_POLICY_SAP)) {
+                // first fit on every candidate path at once: the starts of free runs of >= n slots by shift-and-AND doubling over
+                // the path's words (run_starts), then the lowest (path, slot) of the wave
+                const int kmax = policy == ORLG_POLICY_SP ? 1 : K;
+                const bool on = pp < kmax && pw < W;
+                int n_l = 1;
+                if (on) n_l = tb.nslots[req_br * ORLG_NSLOT_STRIDE + se_l];
+                u64 r = run_starts<W>(on ? acc : 0ull, n_l, pw);
+                const int below = (S - n_l) - 64 * pw;  // start slots below S - n (exclusive: rmsa_env.py:860-871)
+                r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+                const int best = wave_min_i32(r ? (pp << 10) | (64 * pw + ctz64(r)) : 0x7fffffff);
+                if (best != 0x7fffffff) { a_path = best >> 10; a_slot = best & 1023; }
             } else {
                 int max_free = 0;
                 const int kmax = (policy == ORLG_POLICY_SP || policy == ORLG_POLICY_DEEP_SP) ? 1 : K;
                 for (int idp = 0; idp < kmax; ++idp) {
                     u64 x[W];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * LS + w);
                     int n = __builtin_amdgcn_readlane(my_n, idp);
                     if (policy == ORLG_POLICY_DEEP_SP || policy == ORLG_POLICY_DEEP_SAP) {
                         int len;
@@ -877,7 +947,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 if (policy == ORLG_POLICY_EXT || policy == ORLG_POLICY_PATH_EXT || policy == ORLG_POLICY_DEEP_EXT) {
                     u64 x[W];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a_path * W + w);
+                    for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a_path * LS + w);
                     window_ok = window_free<W>(x, a_slot, n, S);
                 }
                 if (window_ok) {
