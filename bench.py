@@ -219,7 +219,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": "orlg_rmsa_kernel<5,%d>" % {"counters": 0, "network": 1, "full": 2}[args.stats],
+                         "kernel": "orlg_rmsa_kernel_ff<5,%d>" % {"counters": 0, "network": 1, "full": 2}[args.stats],
                          "kernel_ms_per_launch": avg_ms, "algorithmic_bytes_per_env_step": A,
                          "env_steps_per_launch": B * n_per_launch},
             "blocking": {"services_processed": int(stats[0]), "services_accepted": int(stats[1]),

@@ -185,6 +185,27 @@ static rmsa_kernel_t pick_stats(int stats, bool step) {
         default: return step ? orlg_rmsa_kernel<W, 2> : orlg_rmsa_reset_kernel<W, 2>;
     }
 }
+template <int W>
+static rmsa_kernel_t pick_ff_stats(int stats) {
+    switch (stats) {
+        case 0: return orlg_rmsa_kernel_ff<W, 0>;
+        case 1: return orlg_rmsa_kernel_ff<W, 1>;
+        default: return orlg_rmsa_kernel_ff<W, 2>;
+    }
+}
+// the wave-per-environment step kernel that only carries the first-fit policies (k <= 8)
+static rmsa_kernel_t pick_rmsa_ff(int W, int stats) {
+    switch (W) {
+        case 1: return pick_ff_stats<1>(stats);
+        case 2: return pick_ff_stats<2>(stats);
+        case 3: return pick_ff_stats<3>(stats);
+        case 4: return pick_ff_stats<4>(stats);
+        case 5: return pick_ff_stats<5>(stats);
+        case 6: return pick_ff_stats<6>(stats);
+        case 8: return pick_ff_stats<8>(stats);
+        default: return nullptr;
+    }
+}
 static rmsa_kernel_t pick_rmsa(int W, int stats, bool step = true) {
     switch (W) {
         case 1: return pick_stats<1>(stats, step);
@@ -277,7 +298,8 @@ static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
 }
 
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
-    rmsa_kernel_t k = pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
+    const bool ff = p.mode == ORLG_MODE_STEP && p.K <= 8 && (p.policy == ORLG_POLICY_SP || p.policy == ORLG_POLICY_SAP);
+    rmsa_kernel_t k = ff ? pick_rmsa_ff(e->W, p.stats_level) : pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
     // release queue: every lane keeps the earliest entry of its own slots (gl, gl + 16, ...) in registers -- an insert updates
     // the receiving lane's, a release makes the lanes look at their slots again -- and the row the time of its earliest entry
     double lm_t = INF;
-    int lm_q = 0x7fffffff, q_top = 0;  // q_top: slots at or beyond it are empty (the queue fills from slot 0)
+    int lm_q = 0x7fffffff, q_top = 0, q_low = 0;  // slots at or beyond q_top are empty, slots below q_low occupied
     for (int j = gl; j < Q; j += ORLG_GL) {
         const double tq = qtime[j];
         if (tq < lm_t) { lm_t = tq; lm_q = j; }
@@ -368,22 +368,34 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
         {
             // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
             const double rel = req_arrival + req_holding;
+            // every slot below q_low is occupied (an insert raises it past the slot it took, a release lowers it to the slot it
+            // freed), so the scan starts at q_low's chunk -- each row at its own
             bool placed = !accepted;
-            for (int q0 = 0; q0 < Q; q0 += ORLG_GL) {
-                if (ballot(!placed) == 0ull) break;
-                const uint32_t em = row_ballot(__double_as_longlong(qtime[q0 + gl]) == (long long)ORLG_INF_BITS, lane);
-                if (!placed && em) {
-                    const int l = __builtin_ctz(em);
-                    if (gl == l) {
-                        qtime[q0 + l] = rel;
-                        qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
-                        if (rel < lm_t || (rel == lm_t && q0 + l < lm_q)) { lm_t = rel; lm_q = q0 + l; }
+            int q0 = q_low & ~(ORLG_GL - 1);
+            while (ballot(!placed) != 0ull) {
+                const bool scan = !placed && q0 < Q;
+                double tq = 0.0;
+                if (scan) tq = qtime[q0 + gl];
+                const uint32_t em = row_ballot(scan && __double_as_longlong(tq) == (long long)ORLG_INF_BITS, lane);
+                if (!placed) {
+                    if (q0 >= Q) {
+                        q_overflow = 1;
+                        placed = true;
+                    } else if (em) {
+                        const int l = __builtin_ctz(em);
+                        if (gl == l) {
+                            qtime[q0 + l] = rel;
+                            qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
+                            if (rel < lm_t || (rel == lm_t && q0 + l < lm_q)) { lm_t = rel; lm_q = q0 + l; }
+                        }
+                        q_top = q0 + l + 1 > q_top ? q0 + l + 1 : q_top;
+                        q_low = q0 + l + 1;
+                        placed = true;
+                    } else {
+                        q0 += ORLG_GL;
                     }
-                    q_top = q0 + l + 1 > q_top ? q0 + l + 1 : q_top;
-                    placed = true;
                 }
             }
-            if (!placed) q_overflow = 1;
             if (accepted) next_rel = rel < next_rel ? rel : next_rel;
             wave_sync();
         }
@@ -477,6 +489,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                 const int n2 = tb.nslots[bri2 * ORLG_NSLOT_STRIDE + rec2->se];
                 if (rel_now) {
                     if (gl == (bq & 15)) qtime[bq] = INF;
+                    q_low = bq < q_low ? bq : q_low;
                     n_running -= 1;
                     sum_bitrate_running -= tb.bit_rates[bri2];
                     sum_sh -= n2 * hops2;

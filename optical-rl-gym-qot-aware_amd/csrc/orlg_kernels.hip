@@ -708,7 +708,9 @@ __device__ unsigned long long orlg_sections[16];
 // ---------------------------------------------------------------------------------------- the step kernel
 // STEPK: the step kernel proper (mode STEP); the reset kernel (modes INIT / EPISODE_RESET: reset(), rmsa_env.py:343-457) is the
 // same body without the policy / provisioning part, under its own name so that kernel statistics keep the two apart.
-template <int W, int STATS, bool STEPK>
+// FF: an instantiation that only knows the first-fit policies (shortest path / shortest available path, k <= 8): the other
+// policies' code -- and the registers it pins -- is gone from the kernel the headline workload runs.
+template <int W, int STATS, bool STEPK, bool FF = false>
 DEV void rmsa_body(const OrlgParams &p) {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef ORLG_SHAPE_ASSUME
@@ -735,7 +737,7 @@ DEV void rmsa_body(const OrlgParams &p) {
     wv.ring_req = reinterpret_cast<uint32_t *>(wv.ring_ht + ORLG_RING);
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
-    const int LS = K <= 8 ? 8 : W;  // lanes from one candidate path to the next in the policy's (path, word) layout
+    const int LS = (FF || K <= 8) ? 8 : W;  // lanes from one candidate path to the next in the policy's (path, word) layout
     constexpr bool NET = STATS >= 1;
     constexpr bool FULL = STATS >= 2;
     SEC_DECL
@@ -869,7 +871,17 @@ DEV void rmsa_body(const OrlgParams &p) {
 
             int a_path = K, a_slot = S;  // rejection (rmsa_env.py:871,913)
             const int policy = p.policy;
-            if (policy == ORLG_POLICY_EXT) {
+            if (FF) {
+                const int kmax = policy == ORLG_POLICY_SP ? 1 : K;
+                const bool on = pp < kmax && pw < W;
+                int n_l = 1;
+                if (on) n_l = tb.nslots[req_br * ORLG_NSLOT_STRIDE + se_l];
+                u64 r = run_starts<W>(on ? acc : 0ull, n_l, pw);
+                const int below = (S - n_l) - 64 * pw;
+                r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+                const int best = wave_min_i32(r ? (pp << 10) | (64 * pw + ctz64(r)) : 0x7fffffff);
+                if (best != 0x7fffffff) { a_path = best >> 10; a_slot = best & 1023; }
+            } else if (policy == ORLG_POLICY_EXT) {
                 const int32_t *acts = kernarg_params()->actions;
                 a_path = uni(acts[2 * env]);
                 a_slot = uni(acts[2 * env + 1]);
@@ -944,7 +956,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 const int n = __builtin_amdgcn_readlane(my_n, a_path);
                 // the device policies only propose windows they found free; agent actions are checked (is_path_free)
                 bool window_ok = true;
-                if (policy == ORLG_POLICY_EXT || policy == ORLG_POLICY_PATH_EXT || policy == ORLG_POLICY_DEEP_EXT) {
+                if (!FF && (policy == ORLG_POLICY_EXT || policy == ORLG_POLICY_PATH_EXT || policy == ORLG_POLICY_DEEP_EXT)) {
                     u64 x[W];
 #pragma unroll
                     for (int w = 0; w < W; ++w) x[w] = readlane64(acc, a_path * LS + w);
@@ -1201,6 +1213,10 @@ DEV void rmsa_body(const OrlgParams &p) {
 template <int W, int STATS>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
     rmsa_body<W, STATS, true>(p);
+}
+template <int W, int STATS>
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel_ff(const OrlgParams p) {
+    rmsa_body<W, STATS, true, true>(p);
 }
 template <int W, int STATS>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_reset_kernel(const OrlgParams p) {

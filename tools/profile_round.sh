@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round profile: kernel-trace stats + PMC passes (instruction mix, FETCH_SIZE, WRITE_SIZE) of the default bench workload.
 # Kernel-trace and PMC runs are separate rocprofv3 invocations, as the MI355X guide prescribes.
-# usage (GPU box): bash tools/profile_round.sh <tag> [bench args]
+# usage (GPU box): [KPAT=<kernel name pattern>] bash tools/profile_round.sh <tag> [bench args]
+# KPAT defaults to the wave-per-environment step kernel; KPAT=orlg_rmsa_group_kernel with --batch 65536 profiles the
+# four-environments-per-wave kernel (bench.py's roofline block always describes the headline batch)
 set -e
 tag=$1; shift
 out=gpurun_out/profile_$tag
@@ -14,13 +16,13 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $out/pmc_busy -- python bench.py $ARGS > $out/pmc_busy.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py $ARGS > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py $ARGS > $out/pmc_write.log 2>&1
-python - $out <<'PY'
+python - $out "${KPAT:-orlg_rmsa_kernel}" <<'PY'
 import csv, glob, json, sys, collections
-out = sys.argv[1]
+out, kpat = sys.argv[1], sys.argv[2]
 summary = {"bench": json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])}
 for f in glob.glob(out + "/kt/*/*kernel_stats.csv"):
     summary["kernel_stats"] = [r for r in csv.DictReader(open(f))]
-step = [r for r in csv.DictReader(open(glob.glob(out + "/kt/*/*kernel_trace.csv")[0])) if "orlg_rmsa_kernel" in r["Kernel_Name"]]
+step = [r for r in csv.DictReader(open(glob.glob(out + "/kt/*/*kernel_trace.csv")[0])) if kpat in r["Kernel_Name"]]
 durs = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
 full = [d for d in durs if d > 0.75 * durs[-1]]
 summary["step_kernel"] = {"name": step[0]["Kernel_Name"], "launches": len(durs), "full_launches": len(full),
@@ -31,7 +33,7 @@ for d in ("pmc_inst", "pmc_busy", "pmc_fetch", "pmc_write"):
     for f in glob.glob(out + "/" + d + "/*/*counter_collection.csv"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "orlg_rmsa_kernel" in r["Kernel_Name"]:
+            if kpat in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             v = sorted(v)
@@ -39,7 +41,7 @@ for d in ("pmc_inst", "pmc_busy", "pmc_fetch", "pmc_write"):
             pmc[k] = sum(big) / len(big)
 summary["pmc_per_full_launch"] = pmc
 b = summary["bench"]
-es = b["roofline"]["env_steps_per_launch"]
+es = b["config"]["batch_per_gpu"] * b["config"]["chunk"]
 summary["per_env_step"] = {k: v / es for k, v in pmc.items()}
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads (guide: x2); the
