@@ -45,7 +45,8 @@ struct orlg_env {
     int resident_blocks;   // workgroups of the step kernel the device keeps resident (grid size of the work queue)
     // four-environments-per-wave step kernel: workgroup shape, LDS bytes, resident workgroups; group_mode = ORLG_KERNEL_*
     // (AUTO falls back to WAVE when the shape does not fit the kernel's LDS budget)
-    int group_mode, group_wpb, group_resident_blocks;
+    int group_mode, group_wpb;   // group_wpb: the most waves per workgroup the LDS holds
+    int group_resident[ORLG_GROUP_WAVES + 1];   // resident workgroups by waves per workgroup (0 = not asked yet)
     size_t group_lds_bytes;
     int num_cu;
     uint32_t ticket_base;
@@ -269,21 +270,33 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     rmsa_kernel_t k = pick_group(e->W, p.stats_level);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->group_lds_bytes));
-    const int wpb = e->group_wpb;
-    if (e->group_resident_blocks <= 0) {
-        int nb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->group_lds_bytes));
-        e->group_resident_blocks = (nb > 0 ? nb : 1) * e->num_cu;
-    }
     const int n_quads = (p.B + 3) / 4;
+    // Waves per workgroup: as many as the LDS holds when the batch keeps every CU busy for several rounds (more resident waves
+    // per SIMD hide more latency); fewer when that would leave CUs idle or the last round mostly empty.  A round of w waves per
+    // CU costs about w + 1.5 (measured: 10 waves per CU step 3 % more environments per second than 8); few rounds count whole.
+    int wpb = e->group_wpb;
+    {
+        double best = 1e300;
+        for (int w = e->group_wpb; w >= 1; --w) {
+            const double rounds = (double)n_quads / ((double)e->num_cu * w);
+            const double cost = (rounds < 3.0 ? std::ceil(rounds) : rounds + 0.5) * (w + 1.5);
+            if (cost < best - 1e-9) { best = cost; wpb = w; }
+        }
+    }
+    const size_t lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb * p.g_wave_bytes;
+    if (e->group_resident[wpb] <= 0) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, lds_bytes));
+        e->group_resident[wpb] = (nb > 0 ? nb : 1) * e->num_cu;
+    }
     int nblocks = (n_quads + wpb - 1) / wpb;
-    if (nblocks > e->group_resident_blocks) nblocks = e->group_resident_blocks;
+    if (nblocks > e->group_resident[wpb]) nblocks = e->group_resident[wpb];
     OrlgParams q = p;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
     if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads;  // one draw per quad of environments a wave takes on
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
-    hipLaunchKernelGGL(k, grid, block, e->group_lds_bytes, e->stream, q);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     return ORLG_OK;
 }
@@ -553,13 +566,13 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         p.g_hist = go; go = up16(go + 4 * NBR * 4);
         p.g_lint = go; go = up16(go + p.lint_stride * 4);
         p.g_env_bytes = go;
-        p.g_mt = 4 * go;
-        p.g_wave_bytes = 4 * go + up16(ORLG_MT_N * 4);
+        p.g_mt = up16(ORLG_MT_N * 4);   // the workgroup's MT19937 staging buffer (then its lock word), in front of the waves' regions
+        p.g_wave_bytes = 4 * go;
         e->group_wpb = 0;
-        for (int cand = ORLG_MAX_WAVES_PER_BLOCK; cand >= 1 && !e->group_wpb; cand--)
-            if ((size_t)p.l_shared_bytes + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
-        e->group_lds_bytes = (size_t)p.l_shared_bytes + (size_t)e->group_wpb * p.g_wave_bytes;
-        e->group_resident_blocks = 0;
+        for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb; cand--)
+            if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
+        e->group_lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)e->group_wpb * p.g_wave_bytes;
+        for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = 0;
         e->group_mode = c->step_kernel;
         const char *gm = getenv("ORLG_GROUP_KERNEL");  // tooling override: 0 = WAVE, 1 = GROUP
         if (gm && (gm[0] == '0' || gm[0] == '1')) e->group_mode = gm[0] == '1' ? ORLG_KERNEL_GROUP : ORLG_KERNEL_WAVE;

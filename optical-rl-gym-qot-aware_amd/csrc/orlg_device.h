@@ -106,6 +106,7 @@ struct OrlgParams {
     int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions
     int32_t l_outs;           // byte offset of the staged outs[] array
     // four-environments-per-wave kernel (orlg_group_kernels.hip): byte offsets inside one environment's LDS region, the region's
-    // size, and the wave's region = 4 environments + the MT19937 staging buffer at g_mt
+    // size (a wave's region = 4 environments), and g_mt = size of the workgroup's MT19937 staging buffer, which sits with its
+    // lock word between the tables and the waves' regions
     int32_t g_occ, g_qtime, g_qdesc, g_lstat, g_hist, g_lint, g_env_bytes, g_mt, g_wave_bytes;
 };

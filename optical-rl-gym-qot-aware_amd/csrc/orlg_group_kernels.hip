@@ -201,15 +201,23 @@ DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
 }
 
 template <int W, int STATS>
-__global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_rmsa_group_kernel(const OrlgParams p) {
+#ifndef ORLG_GROUP_WAVES
+#define ORLG_GROUP_WAVES 12  // waves per workgroup at most (LDS decides how many fit): up to 3 per SIMD
+#endif
+__global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3) / 4) void orlg_rmsa_group_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
     const int g = lane >> 4, gl = lane & 15;
     const Tab tb = make_tab(smem, p);
-    unsigned char *wbase = smem + p.l_shared_bytes + (size_t)wib * p.g_wave_bytes;
-    uint32_t *mt_lds = reinterpret_cast<uint32_t *>(wbase + p.g_mt);
+    // one MT19937 staging buffer per workgroup (a refill happens every ~15 steps per wave and takes a fraction of a step),
+    // handed from wave to wave with a lock word behind it: LDS per wave decides how many environments a CU keeps resident
+    uint32_t *mt_lds = reinterpret_cast<uint32_t *>(smem + p.l_shared_bytes);
+    int *mt_lock = reinterpret_cast<int *>(smem + p.l_shared_bytes + p.g_mt);
+    if (threadIdx.x == 0) *mt_lock = 0;
+    __syncthreads();
+    unsigned char *wbase = smem + p.l_shared_bytes + p.g_mt + 16 + (size_t)wib * p.g_wave_bytes;
     unsigned char *eb = wbase + g * p.g_env_bytes;  // this row's environment
     u64 *occ = reinterpret_cast<u64 *>(eb + p.g_occ);
     double *qtime = reinterpret_cast<double *>(eb + p.g_qtime);
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
     constexpr bool NET = STATS >= 1;
     constexpr bool FULL = STATS >= 2;
     const double INF = __longlong_as_double((long long)ORLG_INF_BITS);
-    SEC_DECL
+    SEC_DECL_G
 
     // ------------------------------------------------------------------ work queue over quads of environments
     // quad q = environments 4q .. 4q+3; the first quad of a wave is its own index, the rest come from the ticket counter
@@ -435,12 +443,30 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 2) void orlg_r
                 const int src_lane = ctz64(m) & 48;
                 const int env_s = __builtin_amdgcn_readlane(env, src_lane);
                 int idx_s = __builtin_amdgcn_readlane(mt_idx, src_lane);
-                copy_words(mt_lds, p.mt + (size_t)env_s * ORLG_MT_N, ORLG_MT_N * 4, lane);
+                // the MT19937 state travels HBM -> registers -> (lock) LDS -> registers (unlock) -> HBM: the workgroup's staging
+                // buffer is held for the regeneration and the draws only, not for the HBM round trips
+                static_assert(ORLG_MT_N * 4 == 156 * 16, "MT19937 state = 156 rows of 16 bytes");
+                const uint4 *g_mt = reinterpret_cast<const uint4 *>(p.mt + (size_t)env_s * ORLG_MT_N);
+                uint4 *l_mt = reinterpret_cast<uint4 *>(mt_lds);
+                uint4 m0 = g_mt[lane], m1 = g_mt[lane + 64], m2 = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < 156 - 128) m2 = g_mt[lane + 128];
+                if (lane == 0) {
+                    while (atomicCAS(mt_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                l_mt[lane] = m0; l_mt[lane + 64] = m1;
+                if (lane < 156 - 128) l_mt[lane + 128] = m2;
                 wave_sync();
                 const int got = refill_requests(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
                                                 p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N,
                                                 NBR, p.arrival_lambda, p.holding_lambda);
-                copy_words(p.mt + (size_t)env_s * ORLG_MT_N, mt_lds, ORLG_MT_N * 4, lane);
+                m0 = l_mt[lane]; m1 = l_mt[lane + 64];
+                if (lane < 156 - 128) m2 = l_mt[lane + 128];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's reads of the buffer are done
+                if (lane == 0) atomicExch(mt_lock, 0);
+                uint4 *o_mt = reinterpret_cast<uint4 *>(p.mt + (size_t)env_s * ORLG_MT_N);
+                o_mt[lane] = m0; o_mt[lane + 64] = m1;
+                if (lane < 156 - 128) o_mt[lane + 128] = m2;
                 __threadfence();  // the ring entries written by other lanes are read back through the vector cache below
                 wave_sync();
                 if ((lane & 48) == src_lane) { ring_cnt = got; ring_pos = 0; mt_idx = idx_s; dry = false; }

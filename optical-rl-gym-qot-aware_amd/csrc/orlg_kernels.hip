@@ -694,6 +694,8 @@ DEV void apply_window(Wave &wv, const uint8_t *links, int hops, int s, int n, bo
 // (tools/section_profile.py).  Not compiled into the product library.
 #ifdef ORLG_SECTIONS
 __device__ unsigned long long orlg_sections[16];
+#define SEC_DECL_G __shared__ unsigned long long sec_acc[16][16]; long long sec_t0 = 0; int sec_cur = 0; \
+    if (lane < 16) sec_acc[wib][lane] = 0ull; wave_sync(); sec_t0 = __builtin_readcyclecounter();
 #define SEC_DECL __shared__ unsigned long long sec_acc[ORLG_MAX_WAVES_PER_BLOCK][16]; long long sec_t0 = 0; int sec_cur = 0; \
     if (lane < 16) sec_acc[wib][lane] = 0ull; wave_sync(); sec_t0 = __builtin_readcyclecounter();
 #define SEC(i) do { const long long sec_n = __builtin_readcyclecounter(); if (lane == 0) sec_acc[wib][sec_cur] += (unsigned long long)(sec_n - sec_t0); \
@@ -701,6 +703,7 @@ __device__ unsigned long long orlg_sections[16];
 #define SEC_FLUSH do { SEC(0); wave_sync(); if (lane < 16) atomicAdd(&orlg_sections[lane], sec_acc[wib][lane]); } while (0)
 #else
 #define SEC_DECL
+#define SEC_DECL_G
 #define SEC(i) do { } while (0)
 #define SEC_FLUSH do { } while (0)
 #endif
