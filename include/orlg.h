@@ -70,9 +70,9 @@ typedef struct orlg_rmsa_config {
 } orlg_rmsa_config;
 
 /* Two step kernels share one state format.  WAVE: one wavefront per environment (every policy).  GROUP: four environments
- * per wavefront, 16 lanes each (shortest-path / shortest-available-path first fit and external (path, slot) actions; the other
- * policies run on WAVE).  AUTO picks GROUP for those policies unless the batch fits the WAVE kernel's resident wavefronts in
- * a launch of more than 16 steps, where WAVE's shorter per-step latency wins.  Results are identical bit for bit. */
+ * per wavefront, 16 lanes each (every policy but load balancing, which runs on WAVE).  AUTO picks GROUP for launches of more
+ * than 16 steps over a batch larger than the WAVE kernel's resident wavefronts (4096 on MI355X), WAVE otherwise.  Results are
+ * identical bit for bit. */
 enum { ORLG_KERNEL_AUTO = 0, ORLG_KERNEL_WAVE = 1, ORLG_KERNEL_GROUP = 2 };
 
 enum {

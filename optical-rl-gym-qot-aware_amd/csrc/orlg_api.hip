@@ -279,7 +279,8 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
         double best = 1e300;
         for (int w = e->group_wpb; w >= 1; --w) {
             const double rounds = (double)n_quads / ((double)e->num_cu * w);
-            const double cost = (rounds < 3.0 ? std::ceil(rounds) : rounds + 0.5) * (w + 1.5);
+            // (short launches stride statically over the quads: whole rounds; long ones draw tickets: the last round is partial)
+            const double cost = ((rounds < 3.0 || p.n_steps <= 16) ? std::ceil(rounds) : rounds + 0.5) * (w + 1.5);
             if (cost < best - 1e-9) { best = cost; wpb = w; }
         }
     }
@@ -303,11 +304,13 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
 
 static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
     if (e->group_mode == ORLG_KERNEL_WAVE || p.mode != ORLG_MODE_STEP) return false;
-    if (p.policy != ORLG_POLICY_EXT && p.policy != ORLG_POLICY_SP && p.policy != ORLG_POLICY_SAP) return false;
+    if (p.policy == ORLG_POLICY_LLP) return false;  // the only policy the four-environments-per-wave kernel does not carry
     if (e->group_mode == ORLG_KERNEL_GROUP) return true;
-    // AUTO: a long launch over a batch that fits the wave-per-environment kernel's resident waves is bound by the latency of
-    // one environment's step chain, which is shorter there; everything else is bound by throughput, which is higher here
-    return !(p.n_steps > 16 && p.B <= e->resident_blocks * e->waves_per_block);
+    // AUTO: this kernel's advantage is throughput once the batch exceeds what the wave-per-environment kernel keeps resident
+    // (604 vs 412 M env-steps/s at B = 4096, 507 vs 780 M at B = 8192, 601 vs 916 M at B = 65 536).  A launch of a few steps
+    // is dominated by moving the state between HBM and LDS, where a whole wave per environment is as good or better (B = 32 768,
+    // one step per launch: 245 vs 236 M).
+    return p.n_steps > 16 && p.B > e->resident_blocks * e->waves_per_block;
 }
 
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {

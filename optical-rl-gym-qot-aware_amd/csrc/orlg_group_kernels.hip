@@ -16,8 +16,9 @@
 // arrivals stay in HBM: a row reads its next arrival one step ahead, and a refill (every ~62 steps per environment) is done
 // by the whole wave for one environment at a time through a per-wave LDS staging buffer (refill_requests, unchanged).
 //
-// Policies: the first-fit family (shortest path / shortest available path) and external (path, slot) actions.  Everything
-// else runs on the wave-per-environment kernel.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
+// Policies: the first-fit family (shortest path / shortest available path, path-only agent actions), the DeepRMSA block family
+// (its two heuristics and the agent's (path, block) action) and external (path, slot) actions.  Load balancing (llp_ff) runs on the
+// wave-per-environment kernel.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
 #pragma once
 #include "orlg_kernels.hip"
 
@@ -31,6 +32,9 @@ DEV int row_min_i32(int v) {
     o = dpp_half_mirror(v); v = o < v ? o : v;
     o = dpp_row_mirror(v); return o < v ? o : v;
 }
+// the value K lanes back in the row (0 before the row's start): DPP row_shr:K
+template <int K>
+DEV int lane_back_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + K, 0xf, 0xf, true); }
 // votes of the lane's own row (16 bits)
 DEV uint32_t row_ballot(bool p, int lane) { return (uint32_t)(ballot(p) >> (lane & 48)) & 0xffffu; }
 // row minimum of (time, slot), ties to the lower slot: the minimum time first, then the lowest slot among the lanes that hold it
@@ -315,23 +319,60 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             a_slot = p.actions[2 * env + 1];
         } else {
             constexpr int PP = ORLG_GL / W;  // candidate paths per pass
-            const int kmax = policy == ORLG_POLICY_SP ? 1 : K;
+            // The first-fit family: the lowest start of a free window of n slots below S - n on the first path that has one
+            // (rmsa_env.py:854-913), over one given path for PathOnlyFirstFitAction (rmsa_env.py:982-1005).  The DeepRMSA family
+            // (deeprmsa_env.py:48-58, rmsa_env.py:774-804): the start of the b-th free BLOCK (maximal free run) of >= n slots --
+            // block 0 of the first path that has one for the heuristics, block a % j of path a / j for an agent action.
+            const bool deep = policy == ORLG_POLICY_DEEP_SP || policy == ORLG_POLICY_DEEP_SAP || policy == ORLG_POLICY_DEEP_EXT;
+            const bool given = policy == ORLG_POLICY_PATH_EXT || policy == ORLG_POLICY_DEEP_EXT;  // the agent names the path
+            int path0 = 0, blk = 0;
+            bool a_ok = true;
+            if (given) {
+                const int a = p.actions[env];
+                if (policy == ORLG_POLICY_DEEP_EXT) {
+                    a_ok = a >= 0 && a < K * p.j;
+                    path0 = a_ok ? a / p.j : 0;
+                    blk = a_ok ? a - path0 * p.j : 0;
+                } else {
+                    a_ok = a >= 0 && a < K;
+                    path0 = a_ok ? a : 0;
+                }
+            }
+            const int kmax = (given || policy == ORLG_POLICY_SP || policy == ORLG_POLICY_DEEP_SP) ? 1 : K;
             const int ps = gl / W, w = gl - ps * W;
             int found = 0x7fffffff;
             for (int p0 = 0; p0 < kmax; p0 += PP) {
-                if (ballot(act && found == 0x7fffffff) == 0ull) break;
+                if (ballot(act && a_ok && found == 0x7fffffff) == 0ull) break;
                 const int pp = p0 + ps;
-                const bool on = ps < PP && pp < kmax;
+                const bool on = ps < PP && pp < kmax && a_ok;
                 int se_pp, hops_pp;
-                const u64 x = path_word_rec<W>(occ, tb.recs, base + pp, w, on, se_pp, hops_pp);
+                const u64 x = path_word_rec<W>(occ, tb.recs, base + path0 + pp, w, on, se_pp, hops_pp);
                 int n = 1;
                 if (on) n = tb.nslots[req_br * ORLG_NSLOT_STRIDE + se_pp];
                 u64 r = run_starts<W>(x, n, w);
-                // start slots below S - n (exclusive: rmsa_env.py:860-871)
-                const int below = (S - n) - 64 * w;
-                r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+                const u64 xprev = lane_prev_u64(x);
+                if (!deep) {
+                    // start slots below S - n (exclusive: rmsa_env.py:860-871)
+                    const int below = (S - n) - 64 * w;
+                    r &= below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+                } else {
+                    // block starts: free slots whose predecessor is not free
+                    r &= x & ~((x << 1) | (w > 0 ? xprev >> 63 : 0ull));
+                    if (policy == ORLG_POLICY_DEEP_EXT) {
+                        // the blk-th block of the path (its words are the row's first W lanes): blocks in the words before this one
+                        const int cntw = popc64(r);
+                        int incl = cntw, o;
+                        o = lane_back_i32<1>(incl); incl += o;
+                        o = lane_back_i32<2>(incl); incl += o;
+                        o = lane_back_i32<4>(incl); incl += o;
+                        const int kth = blk - (incl - cntw);  // which block of this word
+                        for (int q = 0; q < p.j; ++q)
+                            if (q < kth) r &= r - 1;
+                        if (kth < 0 || kth >= cntw) r = 0ull;
+                    }
+                }
                 // key: (path, start slot) decide; the path's slot count and hops ride along in the low bits
-                const int cand = r ? ((((pp << 10) | (64 * w + ctz64(r))) << 14) | (n << 4) | hops_pp) : 0x7fffffff;
+                const int cand = r ? (((((path0 + pp) << 10) | (64 * w + ctz64(r))) << 14) | (n << 4) | hops_pp) : 0x7fffffff;
                 const int best = row_min_i32(cand);
                 if (found == 0x7fffffff) found = best;
             }

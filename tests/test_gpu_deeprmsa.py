@@ -13,10 +13,22 @@ pytestmark = pytest.mark.gpu
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "deeprmsa_*.npz")))
 
 
+STEP_KERNEL = "auto"
+
+
+@pytest.fixture(autouse=True, params=["wave", "group"])
+def step_kernel(request):
+    """Both step kernels carry the DeepRMSA policies (include/orlg.h ORLG_KERNEL_*): every test runs against each."""
+    global STEP_KERNEL
+    STEP_KERNEL = request.param
+    yield request.param
+    STEP_KERNEL = "auto"
+
+
 def make_env(topo, meta_kw, batch):
     from optical_rl_gym_amd import BatchedDeepRMSAEnv
     kw = dict(meta_kw)
-    return BatchedDeepRMSAEnv(topo, batch, **kw)
+    return BatchedDeepRMSAEnv(topo, batch, step_kernel=STEP_KERNEL, **kw)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -69,7 +81,7 @@ def test_deeprmsa_observation_batch_32768(device_log_in_oracle):
     kw = dict(j=1, mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 24.0,
               num_spectrum_resources=320, episode_length=50, seed=100)
     B = 32768
-    env = BatchedDeepRMSAEnv(topo, B, **kw)
+    env = BatchedDeepRMSAEnv(topo, B, step_kernel=STEP_KERNEL, **kw)
     env.run("deeprmsa_sap_ff", 300, auto_reset=True)
     obs = env.observation()
     assert obs.shape == (B, 54)

@@ -7,13 +7,14 @@ from conftest import load_golden, load_topology, oracle_env_from_kwargs
 pytestmark = pytest.mark.gpu
 
 
-def test_wrappers_batched_and_view():
+@pytest.mark.parametrize("step_kernel", ["wave", "group"])
+def test_wrappers_batched_and_view(step_kernel):
     import optical_rl_gym_amd as pkg
     z, meta = load_golden("wrappers_nsfnet_s21")
     topo = load_topology(meta["topology"])
     kw = {k: v for k, v in meta["env_kwargs"].items() if k != "allow_rejection"}
     B = 5
-    env = pkg.BatchedRMSAEnv(topo, B, **kw)
+    env = pkg.BatchedRMSAEnv(topo, B, step_kernel=step_kernel, **kw)
     oracles = [oracle_env_from_kwargs(topo, meta["env_kwargs"], seed=kw["seed"] + i) for i in range(B)]
     rng = np.random.default_rng(9)
     for t in range(300):
