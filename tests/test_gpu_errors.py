@@ -21,6 +21,26 @@ def test_rmsa_queue_overflow_is_reported(nsfnet):
     env.close()
 
 
+def test_group_kernel_overflow_and_lds_limit(nsfnet):
+    """The four-environments-per-wave kernel reports a full release queue like the other one, and a shape whose four
+    environments do not fit the LDS is refused when that kernel is demanded (AUTO falls back to the wave-per-environment kernel)."""
+    from optical_rl_gym_amd import OrlgError
+    kw = dict(num_spectrum_resources=320, load=150, mean_service_holding_time=25, episode_length=1000, seed=1)
+    env = make_batched(nsfnet, kw, 16, queue_capacity=64, step_kernel="group")
+    env.run("sap_ff", 3000)
+    with pytest.raises(OrlgError) as ei:
+        env.reduce_counters()
+    assert ei.value.code == -4 and "queue" in str(ei.value)
+    env.close()
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=1)
+    with pytest.raises(OrlgError) as ei:
+        make_batched(nsfnet, kw, 8, queue_capacity=4096, step_kernel="group")
+    assert ei.value.code == -1 and "LDS" in str(ei.value)
+    env = make_batched(nsfnet, kw, 8, queue_capacity=4096, step_kernel="auto")
+    env.run("sap_ff", 50)
+    env.close()
+
+
 def test_rmsa_limits_are_refused(nsfnet):
     from optical_rl_gym_amd import OrlgError
     for bad in (dict(num_spectrum_resources=513), dict(num_spectrum_resources=0), dict(load=0)):
