@@ -32,9 +32,6 @@ DEV int row_min_i32(int v) {
     o = dpp_half_mirror(v); v = o < v ? o : v;
     o = dpp_row_mirror(v); return o < v ? o : v;
 }
-// the value K lanes back in the row (0 before the row's start): DPP row_shr:K
-template <int K>
-DEV int lane_back_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + K, 0xf, 0xf, true); }
 // votes of the lane's own row (16 bits)
 DEV uint32_t row_ballot(bool p, int lane) { return (uint32_t)(ballot(p) >> (lane & 48)) & 0xffffu; }
 // row minimum of (time, slot), ties to the lower slot: the minimum time first, then the lowest slot among the lanes that hold it

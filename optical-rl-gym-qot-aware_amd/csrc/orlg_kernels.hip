@@ -448,6 +448,8 @@ DEV int lane_prev_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0
 DEV int lane_next_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
 template <int K>
 DEV int lane_ahead_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + K, 0xf, 0xf, true); }
+template <int K>
+DEV int lane_back_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + K, 0xf, 0xf, true); }   // K lanes back (row_shr:K)
 DEV u64 lane_prev_u64(u64 v) {
     const uint32_t lo = (uint32_t)lane_prev_i32((int)(uint32_t)v), hi = (uint32_t)lane_prev_i32((int)(uint32_t)(v >> 32));
     return ((u64)hi << 32) | lo;
@@ -1283,33 +1285,81 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
         wave_sync();
         const int mn = src < dst ? src : dst, mx = src < dst ? dst : src;
         const int base = tb.pair_base[src * N + dst];
-        const int pp = lane / W, pw = lane - pp * W;
-        u64 acc = 0ull;
-        acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-        int my_se = 0;
-        if (lane < K) my_se = tb.recs[base + lane].se;
-        int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
-        for (int idp = 0; idp < K; ++idp) {
-            u64 x[W];
+        if (K <= 8) {
+            // every candidate path at once: path g on the 8-lane group g (two groups per DPP row), one word per lane
+            const int g8 = lane >> 3, w = lane & 7;
+            const bool on = g8 < K && w < W;
+            int se_l, hops_l;
+            const u64 x = path_word_rec<W>(occ, tb.recs, base + g8, w, on, se_l, hops_l);
+            int n = 1;
+            if (on) n = tb.nslots[br * ORLG_NSLOT_STRIDE + se_l];
+            const u64 xprev = lane_prev_u64(x);
+            const u64 starts = x & ~((x << 1) | (w > 0 ? xprev >> 63 : 0ull));   // first slots of the free runs
+            const u64 bs = starts & run_starts<W>(x, n, w);                        // ... of those with >= n slots: the blocks
+            // free slots continuing a run that reaches this word's end (as in link_stats_update)
+            const int lead = x == ~0ull ? 64 : ctz64(~x);
+            const int nlead_raw = lane_next_i32(lead);
+            const int nlead = w < W - 1 ? nlead_raw : 0;
+            int e = nlead;
 #pragma unroll
-            for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
-            const int n = __builtin_amdgcn_readlane(my_n, idp);
-            int *row = opa + head + idp * PW;
+            for (int i = 0; i < W - 2; ++i) {
+                const int ne_raw = lane_next_i32(e);
+                const int ne = w < W - 1 ? ne_raw : 0;
+                e = nlead == 64 ? 64 + ne : nlead;
+            }
+            // blocks in the words before this one (prefix sum over the group's lanes)
+            const int cnt = popc64(bs);
+            int incl = cnt, o;
+            o = lane_back_i32<1>(incl); if (w >= 1) incl += o;
+            o = lane_back_i32<2>(incl); if (w >= 2) incl += o;
+            o = lane_back_i32<4>(incl); if (w >= 4) incl += o;
+            const int n_blocks = group8_add(cnt), total = group8_add(popc64(x)), runs = group8_add(popc64(starts));
+            int *row = opa + head + g8 * PW;
             for (int b = 0; b < J; ++b) {
-                int len = 0;
-                int s0 = find_block<W>(x, n, b, lane, &len);
-                if (lane == 0) { row[2 * b] = s0; row[2 * b + 1] = s0 >= 0 ? len : -1; }
+                const int kth = b - (incl - cnt);   // which block of this word
+                u64 m = bs;
+                for (int q = 0; q < J; ++q)
+                    if (q < kth) m &= m - 1;
+                if (on && kth >= 0 && kth < cnt) {
+                    const int sb = ctz64(m);
+                    row[2 * b] = 64 * w + sb;
+                    row[2 * b + 1] = free_run_length((~x) >> sb, 64 - sb + e);
+                }
+                if (on && w == 0 && b >= n_blocks) { row[2 * b] = -1; row[2 * b + 1] = -1; }
             }
-            int total = 0, runs = 0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                u64 carry = w > 0 ? (x[w > 0 ? w - 1 : 0] >> 63) : 0ull;
-                total += popc64(x[w]);
-                runs += popc64(x[w] & ~((x[w] << 1) | carry));
-            }
-            if (lane == 0) {
+            if (on && w == 0) {
                 row[2 * J] = n; row[2 * J + 1] = total; row[2 * J + 2] = total;
-                opb[head + idp * PW + 2 * J + 2] = runs;
+                opb[head + g8 * PW + 2 * J + 2] = runs;
+            }
+        } else {
+            const int pp = lane / W, pw = lane - pp * W;
+            u64 acc = 0ull;
+            acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
+            int my_se = 0;
+            if (lane < K) my_se = tb.recs[base + lane].se;
+            int my_n = tb.nslots[br * ORLG_NSLOT_STRIDE + my_se];
+            for (int idp = 0; idp < K; ++idp) {
+                u64 x[W];
+    #pragma unroll
+                for (int w = 0; w < W; ++w) x[w] = readlane64(acc, idp * W + w);
+                const int n = __builtin_amdgcn_readlane(my_n, idp);
+                int *row = opa + head + idp * PW;
+                for (int b = 0; b < J; ++b) {
+                    int len = 0;
+                    int s0 = find_block<W>(x, n, b, lane, &len);
+                    if (lane == 0) { row[2 * b] = s0; row[2 * b + 1] = s0 >= 0 ? len : -1; }
+                }
+                int total = 0, runs = 0;
+    #pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    u64 carry = w > 0 ? (x[w > 0 ? w - 1 : 0] >> 63) : 0ull;
+                    total += popc64(x[w]);
+                    runs += popc64(x[w] & ~((x[w] << 1) | carry));
+                }
+                if (lane == 0) {
+                    row[2 * J] = n; row[2 * J + 1] = total; row[2 * J + 2] = total;
+                    opb[head + idp * PW + 2 * J + 2] = runs;
+                }
             }
         }
         wave_sync();
