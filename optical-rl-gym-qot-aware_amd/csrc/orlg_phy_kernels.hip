@@ -960,6 +960,11 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     int head_level[ORLG_PHY_MAX_K];
                     double head_metric[ORLG_PHY_MAX_K];
                     unsigned alive = 0;
+                    // the row the first pick below will choose keeps its per-channel (level, metric) values: no second pass
+                    int keep_idp = -1, keep_lv[W], keep_l = -1;
+                    double keep_mt[W], keep_m = 0.0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) { keep_lv[w] = -1; keep_mt[w] = 0.0; }
 #pragma unroll
                     for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
                         head_level[idp] = -1; head_metric[idp] = 0.0;
@@ -970,7 +975,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             int bl, bc;
                             double bm;
                             phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
-                            if (bl >= 0) { head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp; }
+                            if (bl >= 0) {
+                                head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp;
+                                if (keep_idp < 0 || (!first_row && (bl > keep_l || (with_metric && bl == keep_l && bm > keep_m)))) {
+                                    keep_idp = idp; keep_l = bl; keep_m = bm;
+#pragma unroll
+                                    for (int w = 0; w < W; ++w) { keep_lv[w] = lv[w]; keep_mt[w] = mtr[w]; }
+                                }
+                            }
                         }
                     }
                     SEC(4);  // policy: channel selection
@@ -989,7 +1001,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         int lv[W];
                         double mtr[W];
                         const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
-                        phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w);
+                        if (best == keep_idp) {
+#pragma unroll
+                            for (int w = 0; w < W; ++w) { lv[w] = keep_lv[w]; mtr[w] = keep_mt[w]; }
+                            keep_idp = -1;
+                        } else {
+                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w);
+                        }
                         int unassigned = demand;
                         nsel = 0;
                         bool covered = false;
