@@ -566,7 +566,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         p.g_qtime = go; go = up16(go + Q * 8);
         p.g_qdesc = go; go = up16(go + Q * 4);
         p.g_lstat = go; if (c->stats_level >= ORLG_STATS_FULL) go = up16(go + 4 * E * 8);
-        p.g_hist = go; go = up16(go + 4 * NBR * 4);
+        p.g_hist = go;   // (unused: the four-environments-per-wave kernel updates the histograms in HBM)
         p.g_lint = go; go = up16(go + p.lint_stride * 4);
         p.g_env_bytes = go;
         p.g_mt = up16(ORLG_MT_N * 4);   // the workgroup's MT19937 staging buffer (then its lock word), in front of the waves' regions

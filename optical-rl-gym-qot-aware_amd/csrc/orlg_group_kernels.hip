@@ -224,7 +224,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     double *qtime = reinterpret_cast<double *>(eb + p.g_qtime);
     uint32_t *qdesc = reinterpret_cast<uint32_t *>(eb + p.g_qdesc);
     double *lst = reinterpret_cast<double *>(eb + p.g_lstat);
-    int32_t *hist = reinterpret_cast<int32_t *>(eb + p.g_hist);
     int32_t *lint = reinterpret_cast<int32_t *>(eb + p.g_lint);
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
@@ -264,7 +263,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     row_copy16(qtime, p.qtime + (size_t)env * Q, Q * 8, gl);
     row_copy16(qdesc, p.qdesc + (size_t)env * Q, Q * 4, gl);
     if (FULL) row_copy16(lst, p.lstat + (size_t)env * 4 * E, 4 * E * 8, gl);
-    row_copy16(hist, p.hist + (size_t)env * 4 * NBR, 4 * NBR * 4, gl);
+    // the bit-rate histograms are only ever incremented (and zeroed at an episode's end): they stay in HBM and take L2 atomics
+    // without return -- 336 bytes of LDS per environment decide how many waves a CU keeps resident.  Every access
+    // is an atomic, so that the updates of one address arrive at L2 in program order.
+    int32_t *ghist = p.hist + (size_t)env * 4 * NBR;
     if (NET) row_copy16(lint, p.lint + (size_t)env * p.lint_stride, p.lint_stride * 4, gl);
     const OrlgEnvScalars *gs = p.scal + env;
     double current_time = gs->current_time, req_arrival = gs->req_arrival, req_holding = gs->req_holding;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             n_running += 1;
             sum_bitrate_running += br_val;
             cnt += (cidx == 1 || cidx == 3) ? 1 : ((cidx == 5 || cidx == 7) ? br_val : 0);
-            if (gl == 0) { hist[NBR + req_br] += 1; hist[3 * NBR + req_br] += 1; }
+            if (gl == 0) { atomicAdd(ghist + NBR + req_br, 1); atomicAdd(ghist + 3 * NBR + req_br, 1); }
         }
         SEC(4);  // statistics at provision
         if (NET)
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 req_arrival = at; req_holding = r_ht;
                 const int bv = tb.bit_rates[req_br];
                 cnt += (cidx == 0 || cidx == 2) ? 1 : ((cidx == 4 || cidx == 6) ? bv : 0);
-                if (gl == 0) { hist[req_br] += 1; hist[2 * NBR + req_br] += 1; }
+                if (gl == 0) { atomicAdd(ghist + req_br, 1); atomicAdd(ghist + 2 * NBR + req_br, 1); }
             }
 
             // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             if (ballot(done && p.auto_reset)) {
                 // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
                 if (done && p.auto_reset) {
-                    for (int i = gl; i < NBR; i += ORLG_GL) { hist[2 * NBR + i] = 0; hist[3 * NBR + i] = 0; }
+                    for (int i = gl; i < NBR; i += ORLG_GL) { atomicExch(ghist + 2 * NBR + i, 0); atomicExch(ghist + 3 * NBR + i, 0); }
                     eproc = 1;
                     episodes_done += 1;
                     const int bv = tb.bit_rates[req_br];
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                     if (cidx == 6) cnt = bv;
                 }
                 wave_sync();
-                if (done && p.auto_reset && gl == 0) hist[2 * NBR + req_br] = 1;
+                if (done && p.auto_reset && gl == 0) atomicExch(ghist + 2 * NBR + req_br, 1);
                 wave_sync();
             }
         }
@@ -605,7 +607,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         row_copy16(p.qtime + (size_t)env * Q, qtime, Q * 8, gl);
         row_copy16(p.qdesc + (size_t)env * Q, qdesc, Q * 4, gl);
         if (FULL) row_copy16(p.lstat + (size_t)env * 4 * E, lst, 4 * E * 8, gl);
-        row_copy16(p.hist + (size_t)env * 4 * NBR, hist, 4 * NBR * 4, gl);
         if (NET) row_copy16(p.lint + (size_t)env * p.lint_stride, lint, p.lint_stride * 4, gl);
         OrlgEnvScalars *go = p.scal + env;
         if (gl < 8) go->c[gl] = cnt;
