@@ -330,3 +330,17 @@ def test_kernels_continue_each_other(nsfnet):
     assert np.array_equal(ref.save_state(), cur.save_state())   # byte for byte: queue slots, RNG state, arrival ring, caches
     for env in (ref, a, b):
         env.close()
+
+
+def test_random_configurations_cross_check(step_kernel):
+    """tools/cross_check_kernels.py: random grids, slot counts, k, loads, policies, batch sizes and launch lengths; the two step
+    kernels must leave byte-identical states after every launch (450 configurations / 41 000 launches were run this way at the
+    end of round 1; the suite keeps a dozen)."""
+    if step_kernel != "wave":
+        pytest.skip("one run covers both kernels")
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cross_check_kernels.py"), "--configs", "12", "--seed", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["configs_checked"] == 12
