@@ -105,8 +105,9 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
             }
         }
         const bool first_free = x & 1ull;                                                     // meaningful on w == 0
-        const int last_free_bit = (int)((x >> ((S - 1) & 63)) & 1ull);
-        const bool last_free = W == 1 ? last_free_bit != 0 : dpp_row_shl<(W > 1 ? W - 1 : 1)>(0, last_free_bit) != 0;  // slot S - 1, seen from w == 0
+        // slot S - 1 sits in word (S - 1) >> 6 -- not always the last of the W words (S = 400 runs on the 8-word layout)
+        const int last_free_bit = w == ((S - 1) >> 6) ? (int)((x >> ((S - 1) & 63)) & 1ull) : 0;
+        const bool last_free = seg_max<W>(last_free_bit) != 0;  // on the link's first lane
         if (on) {
             u64 u = ~x & valid_mask(S, w);
             u64 carry_f = w > 0 ? (prev >> 63) : 0ull;

@@ -96,7 +96,7 @@ def test_two_node_network(tmp_path, device_log_in_oracle):
     _compare(topo, kw, "sap_ff", 300, 4)
 
 
-@pytest.mark.parametrize("slots", [65, 100, 191, 320, 384])
+@pytest.mark.parametrize("slots", [65, 100, 191, 320, 384, 400, 448])   # 400 / 448: seven words of slots on the eight-word layout
 def test_slot_counts_off_the_word_boundary(tmp_path, slots, device_log_in_oracle):
     pytest.importorskip("networkx")
     from optical_rl_gym_amd.topology_io import topology_from_txt
