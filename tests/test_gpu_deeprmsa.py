@@ -97,3 +97,33 @@ def test_deeprmsa_observation_batch_32768(device_log_in_oracle):
         assert np.array_equal(obs[i], o.observation()), i
         o.close()
     env.close()
+
+
+@pytest.mark.parametrize("slots,j", [(400, 2), (200, 3), (64, 1), (512, 2)])
+def test_deeprmsa_synthetic_shapes(tmp_path, slots, j, device_log_in_oracle):
+    """Observation builder and block policies on shapes the golden traces do not have (seven words of slots on the eight-word
+    layout, one word, j > 1 with few blocks): device vs oracle, observation and decisions bit for bit."""
+    pytest.importorskip("networkx")
+    import test_gpu_edge_cases as ec
+    from optical_rl_gym_amd.topology_io import topology_from_txt
+    rng = np.random.default_rng(slots + j)
+    edges = ec._grid_edges(3, 3, rng)
+    topo = topology_from_txt(ec._write_topology(tmp_path, "grid9", 9, edges), "grid9", k_paths=3)
+    meta_kw = dict(j=j, mean_service_holding_time=10.0, mean_service_inter_arrival_time=10.0 / (0.25 * slots),
+                   num_spectrum_resources=slots, episode_length=40, seed=slots)
+    batch = 3
+    env = make_env(topo, meta_kw, batch)
+    kw, jj = deeprmsa_to_rmsa_kwargs(meta_kw)
+    oracles = [oracle_env_from_kwargs(topo, kw, seed=kw["seed"] + i, j=jj, reward_mode=1) for i in range(batch)]
+    for t in range(120):
+        a = rng.integers(0, topo.k_paths * j + 1, batch).astype(np.int32)
+        r = env.run("deeprmsa_external", 1, actions=a, auto_reset=True, outputs=("act_path", "act_slot", "accepted", "reward", "done"))
+        obs = env.observation()
+        for i, o in enumerate(oracles):
+            ot = o.run("deeprmsa_external", 1, reset_on_done=True, actions=a[i:i + 1].copy())
+            for f in ("act_path", "act_slot", "accepted", "reward", "done"):
+                assert r[f][0, i] == ot[f][0], (f, t, i)
+            assert np.array_equal(obs[i], o.observation()), (t, i)
+    for o in oracles:
+        o.close()
+    env.close()
