@@ -593,8 +593,11 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
         }
         const bool first_free = x & 1ull;  // meaningful on the link's first lane
         // slot S - 1 sits in word (S - 1) >> 6 -- not always the last of the W words (S = 400 runs on the 8-word layout)
-        const int last_free_bit = w == ((S - 1) >> 6) ? (int)((x >> ((S - 1) & 63)) & 1ull) : 0;
-        const bool last_free = group8_max(last_free_bit) != 0;
+        const int lw = (S - 1) >> 6;
+        const int last_free_bit = w == lw ? (int)((x >> ((S - 1) & 63)) & 1ull) : 0;
+        bool last_free;
+        if (lw == W - 1) last_free = W == 1 ? last_free_bit != 0 : lane_ahead_i32<(W > 1 ? W - 1 : 1)>(last_free_bit) != 0;  // wave-uniform branch
+        else last_free = group8_max(last_free_bit) != 0;
         if (hl < nl && w < W) {
             u64 u = ~x & valid_mask(S, w);
             u64 carry_f = w > 0 ? (prev >> 63) : 0ull;
