@@ -307,7 +307,7 @@ static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
     if (p.policy == ORLG_POLICY_LLP) return false;  // the only policy the four-environments-per-wave kernel does not carry
     if (e->group_mode == ORLG_KERNEL_GROUP) return true;
     // AUTO: this kernel's advantage is throughput once the batch exceeds what the wave-per-environment kernel keeps resident
-    // (604 vs 435 M env-steps/s at B = 4096, 507 vs 781 M at B = 8192, 601 vs 998 M at B = 65 536).  A launch of a few steps
+    // (595 vs 435 M env-steps/s at B = 4096, 507 vs 781 M at B = 8192, 601 vs 998 M at B = 65 536).  A launch of a few steps
     // is dominated by moving the state between HBM and LDS: there it wins when its LDS footprint leaves it at least 10 waves
     // per CU (B = 32 768, one step per launch: 287 vs 250 M with 11 waves; DeepRMSA's 192-slot queue leaves 9: 0.170 vs 0.166 ms).
     if (p.B <= e->resident_blocks * e->waves_per_block) return false;
