@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- env steps/s of the batched RMSA step() hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chunk T] [--stats full|network|counters]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chunk T] [--mixed] [--only NAME] [--dry-run]
 
-One "step" = every environment of the batch advances by one RMSAEnv.step (policy -> provision ->
-release -> next arrival, all statistics) -- K steps are executed as ceil(K / chunk) launches of the
-persistent step kernel (chunk env-steps per launch).  Workload at N=1: BASELINE.json configs[1]
-(RMSA-v0, NSFNET, 320 slots, load 50, B = 4096 envs per GPU, shortest-available-path first-fit run on
-the device, seeds 10 + i).  Inputs are synthetic (the reference's own Poisson traffic generator run on
-the device) and all state is resident in HBM before the timed region starts.
+One bench "step" = ONE LAUNCH of the persistent step kernel = every environment of the batch advances by `chunk`
+(default 1000) RMSAEnv.step calls (policy -> provision -> release -> next arrival, all statistics).  K timed launches
+follow W >= 1 untimed launches of the same shape (so every environment has made >= 300 steps -- SURVEY 8(d) config 2 --
+and the network is in its steady state before the clock starts); ms_per_step x K = the timed region.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; envs shard across ranks
-with no data-path communication ("weak" scaling: B per GPU fixed); the only collective is the RCCL
-all-reduce of the episode statistics vector at the end (orlg_reduce_counters).
+Headline workload at N=1: the batch BASELINE.json's north_star quotes its target on -- RMSA-v0, NSFNET, 320 slots,
+load 50, B = 65 536 environments per GPU, shortest-available-path first fit run on the device, seeds 10 + i, full
+statistics.  Sub-records (N=1 only), each timed the same way with its own roofline block and kernel name:
+    rmsa_b4096        BASELINE configs[1] (the same env x 4096)
+    phy_us14_b4096    BASELINE configs[2]: QoT-aware RMSA, US14, load 1400, bmfa -- with number_cuts_total / rss_total_metric
+                      written every step as the reference's step() does (lead), without them, and with the periodic
+                      defragmentation (defrag_period 10, number_moves 10)
+    deeprmsa_b32768   BASELINE configs[3]: one launch + one observation build per step; also the PCIe-inclusive rate of
+                      the agent loop (actions from host memory, observations copied back)
+Inputs are synthetic (the reference's own Poisson traffic generator run on the device) and all state is resident in HBM
+before the timed region starts.
+
+N > 1: one process per GPU (the driver launches them with torch.distributed.run; `python bench.py --gpus N` without
+WORLD_SIZE in the environment starts them itself, as fresh child processes, before anything touches a GPU).  Environments
+shard across ranks with no data-path communication ("weak" scaling: B per GPU fixed, seeds base + rank*B + i); the only
+collective is the RCCL all-reduce of the episode statistics vector.  --mixed: BASELINE configs[4], one topology group per
+rank (NSFNET / JPN12 / US14 by rank mod 3).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,15 +43,292 @@ TOPOLOGY = "nsfnet_chen_5-paths_6-modulations"
 # --mixed (BASELINE configs[4]): one topology group per rank, rank r takes MIXED[r % 3]; "JPN48" is not shipped with the
 # reference, jpn12 stands in
 MIXED = ("nsfnet_chen_5-paths_6-modulations", "jpn12_5-paths_6-modulations", "us14_3-paths_6-modulations")
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles per SIMD (measured: SQ_ACTIVE_INST_VALU = 4.2
+# cycles per VALU instruction on these kernels), 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 
 
-def algorithmic_bytes_per_env_step(topo, W):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20, help="timed launches (one launch = chunk env-steps per environment)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed launches of the same shape (at least 1)")
+    ap.add_argument("--batch", type=int, default=65536, help="environments per GPU")
+    ap.add_argument("--chunk", type=int, default=1000, help="env steps per kernel launch")
+    ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
+    ap.add_argument("--policy", default="sap_ff")
+    ap.add_argument("--step-kernel", default="auto", choices=["auto", "wave", "group"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="headline only")
+    ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "deeprmsa"],
+                    help="run one workload only (profiling)")
+    ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: ranks report their shard through gloo (launcher test)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes with torch.distributed.run as a CHILD process
+    (this parent never touches a GPU) and pass rank 0's JSON line through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    return r.returncode
+
+
+def dry_run(args, rank, world):
+    """The launcher and the sharding without a GPU: every rank reports its shard, rank 0 prints one line."""
+    from optical_rl_gym_amd.distributed import shard_base_seed
+    import numpy as np
+    B = args.batch
+    mine = {"rank": rank, "world": world, "topology": MIXED[rank % 3] if args.mixed else TOPOLOGY,
+            "first_seed": shard_base_seed(10, B, rank), "last_seed": shard_base_seed(10, B, rank) + B - 1}
+    vec = np.zeros(16, np.int64)
+    vec[9] = B
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        from optical_rl_gym_amd.distributed import allreduce_stats
+        vec = allreduce_stats(vec, dist, None)
+        shards = [None] * world
+        dist.all_gather_object(shards, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        shards = [mine]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "num_envs": int(vec[9]), "shards": shards}), flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ accounting
+def algorithmic_bytes_per_env_step(topo, W, extra=0.0):
     """read the env's occupancy once + RMW on provision and release over the mean
-    hop count + service record + request record + action/reward/done."""
+    hop count + service record + request record + action/reward/done (+ `extra`: table rows / observation)."""
     import numpy as np
     E = topo.num_links
     hbar = float(np.mean(topo.path_hops))
-    return E * W * 8 + 2 * 2 * hbar * W * 8 + 48 + 40 + 16
+    return E * W * 8 + 2 * 2 * hbar * W * 8 + 48 + 40 + 16 + extra
+
+
+def load_pmc(key):
+    """Per-env-step counters of this workload from the committed rocprofv3 PMC summary (profiles/pmc.json, written by
+    tools/collect_profile.py from the passes of tools/profile_round.sh)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc.json")))["entries"].get(key)
+    except Exception:
+        return None
+
+
+def roofline_block(key, kernel, kernel_ms, A, env_steps_per_launch, batch):
+    """HBM roofline by the SURVEY 8(d) accounting (what the contract asks for) + what the counters say binds the kernel."""
+    achieved = A * env_steps_per_launch / (kernel_ms * 1e-3) / 1e9
+    rate = env_steps_per_launch / (kernel_ms * 1e-3)
+    rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+          "traffic": None, "traffic_unit": "bytes per launch", "kernel": kernel, "kernel_ms_per_launch": kernel_ms,
+          "algorithmic_bytes_per_env_step": A, "env_steps_per_launch": env_steps_per_launch,
+          "note": "bound/achieved/frac follow SURVEY 8(d)'s algorithmic-byte accounting; the state lives in LDS for a whole "
+                  "launch, so measured HBM traffic is far below it and the binding resource is VALU issue (valu_issue block)"}
+    pmc = load_pmc(key)
+    if pmc and pmc.get("batch") == batch:
+        per = pmc["per_env_step"]
+        if "hbm_bytes" in per:
+            rl["traffic"] = per["hbm_bytes"] * env_steps_per_launch
+            rl["hbm_measured_GBps"] = per["hbm_bytes"] * rate / 1e9
+            rl["traffic_source"] = pmc.get("source")
+        if "SQ_INSTS_VALU" in per:
+            ginst = per["SQ_INSTS_VALU"] * rate / 64.0 / 1e9 if pmc.get("insts_are_per_lane") else per["SQ_INSTS_VALU"] * rate / 1e9
+            rl["valu_issue"] = {"bound": "valu_issue", "valu_insts_per_env_step": per["SQ_INSTS_VALU"],
+                                "salu_insts_per_env_step": per.get("SQ_INSTS_SALU"), "lds_insts_per_env_step": per.get("SQ_INSTS_LDS"),
+                                "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                                "frac": ginst / VALU_PEAK_GINST, "valu_busy": pmc.get("valu_busy"),
+                                "waves_per_simd": pmc.get("waves_per_simd"), "source": pmc.get("source"),
+                                "peak_note": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave-instruction"}
+    return rl
+
+
+# ------------------------------------------------------------------------------------------------ measurements
+class Clock:
+    """barrier + synchronize on both sides of the timed region, HIP events per launch on the kernels' own stream."""
+
+    def __init__(self, torch, dev, stream, dist):
+        self.torch, self.dev, self.stream, self.dist = torch, dev, stream, dist
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def timed(self, launch, steps):
+        ev = []
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            launch()
+            b.record(self.stream)
+            ev.append((a, b))
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        return elapsed, [a.elapsed_time(b) for a, b in ev]
+
+
+def rmsa_record(clock, topo_name, B, chunk, warm, steps, args, rank, local_rank, key):
+    import numpy as np
+    from conftest import load_topology
+    from optical_rl_gym_amd import BatchedRMSAEnv
+    from optical_rl_gym_amd.distributed import shard_base_seed
+    topo = load_topology(topo_name)
+    env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=shard_base_seed(10, B, rank), stats_level=args.stats, device=local_rank,
+                         step_kernel=args.step_kernel)
+    env.set_stream(clock.stream.cuda_stream)
+    launch = lambda: env.run(args.policy, chunk, auto_reset=True)
+    for _ in range(max(1, warm)):
+        launch()
+    elapsed, kms = clock.timed(launch, steps)
+    red, vec = env.reduce_counters()
+    kernel = env.last_kernel()
+    W = env.words_per_link
+    env.close()
+    A = algorithmic_bytes_per_env_step(topo, W)
+    kernel_ms = float(np.mean(kms))
+    return {"value": B * chunk * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": chunk,
+            "launches_timed": steps, "launches_warmup": max(1, warm), "timed_region_s": elapsed,
+            "ms_per_launch": elapsed * 1e3 / steps, "step_kernel": kernel.split(" ")[0], "launch": kernel,
+            "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),
+            "roofline": roofline_block(key, kernel.split(" ")[0], kernel_ms, A, B * chunk, B)}, vec, elapsed, topo
+
+
+def phy_record(clock, args, variant):
+    """BASELINE configs[2]: PhyRMSA US14 load 1400, B = 4096, bmfa (cut metric) on the device."""
+    import numpy as np
+    import torch
+    from conftest import load_phy_tables, load_topology
+    from optical_rl_gym_amd import BatchedPhyRMSAEnv
+    B, chunk = 4096, 250
+    topo = load_topology("us14_3-paths_6-modulations")
+    pairs, mod, gsnr = load_phy_tables("us14_k3")
+    defrag = variant == "phy_defrag"
+    metrics = variant in ("phy_metrics", "phy_defrag")
+    env = BatchedPhyRMSAEnv(topo, B, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=1400,
+                            mean_service_holding_time=25, episode_length=200, seed=10, grooming=False,
+                            defrag_period=10 if defrag else None, number_moves=10 if defrag else None, metric="cut")
+    env.set_stream(clock.stream.cuda_stream)
+    out = None
+    if metrics:   # the reference's step() computes both every step (phy_rmsa_env.py:319-348): written to device buffers
+        out = {"number_cuts_total": torch.empty((chunk, B), dtype=torch.float64, device=clock.dev),
+               "rss_total_metric": torch.empty((chunk, B), dtype=torch.float64, device=clock.dev)}
+    launch = lambda: env.run("bmfa", chunk, auto_reset=True, out=out)
+    for _ in range(12):   # 3000 steps: load 1400 needs a few thousand arrivals to fill the network
+        launch()
+    # as many launches as make about one second
+    clock.barrier()
+    t0 = time.perf_counter()
+    launch()
+    clock.barrier()
+    one = time.perf_counter() - t0
+    steps = int(min(200, max(4, round(1.0 / max(one, 1e-4)))))
+    elapsed, kms = clock.timed(launch, steps)
+    red, _ = env.reduce_counters()
+    kernel = env.last_kernel()
+    st = env.episode_stats()
+    running = float(env.num_running().mean())
+    env.close()
+    A = algorithmic_bytes_per_env_step(topo, env.words_per_link, extra=268 * topo.k_paths)
+    kernel_ms = float(np.mean(kms))
+    rec = {"value": B * chunk * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": chunk,
+           "launches_timed": steps, "timed_region_s": elapsed, "ms_per_launch": elapsed * 1e3 / steps,
+           "policy": "bmfa (cut metric)", "per_step_metrics": metrics, "defragmentation": "period 10, 10 moves, cut" if defrag else None,
+           "step_kernel": kernel.split(" ")[0], "launch": kernel, "mean_running_services": running,
+           "queue_overflow": int(st["queue_overflow"].max()),
+           "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),
+           "roofline": roofline_block(variant, kernel.split(" ")[0], kernel_ms, A, B * chunk, B)}
+    return rec
+
+
+def deeprmsa_record(clock, args):
+    """BASELINE configs[3]: DeepRMSA-v0 NSFNET S=320 j=1, holding 7.5, inter-arrival 1/12, B = 32768: every step is one
+    step launch (SAP-FF on the device standing in for the agent) + one observation build into a device buffer."""
+    import numpy as np
+    import torch
+    from conftest import DEEPRMSA_NODE_PROBS, load_topology
+    from optical_rl_gym_amd import BatchedDeepRMSAEnv
+    B = 32768
+    topo = load_topology(TOPOLOGY)
+    env = BatchedDeepRMSAEnv(topo, B, num_spectrum_resources=320, j=1, mean_service_holding_time=7.5,
+                             mean_service_inter_arrival_time=1 / 12.0, node_request_probabilities=DEEPRMSA_NODE_PROBS,
+                             episode_length=50, seed=10)
+    env.set_stream(clock.stream.cuda_stream)
+    obs = torch.empty((B, env.obs_dim), dtype=torch.float64, device=clock.dev)
+
+    def step():
+        env.run("deeprmsa_sap_ff", 1, auto_reset=True)
+        env.observation(out=obs)
+    for _ in range(300):
+        step()
+    steps = 3000
+    clock.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    clock.barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel durations on a sample (events between the two launches of a step)
+    ks, ko = [], []
+    evs = []
+    for _ in range(100):
+        a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record(clock.stream)
+        env.run("deeprmsa_sap_ff", 1, auto_reset=True)
+        b.record(clock.stream)
+        env.observation(out=obs)
+        c.record(clock.stream)
+        evs.append((a, b, c))
+    clock.barrier()
+    for a, b, c in evs:
+        ks.append(a.elapsed_time(b)); ko.append(b.elapsed_time(c))
+    step_kernel = env.last_kernel()
+    # the agent loop as an SB3 agent pays it: actions from host memory, observations copied back to host memory
+    acts = np.zeros(B, np.int32)
+    obs_h = np.zeros((B, env.obs_dim), np.float64)
+    for _ in range(20):
+        env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
+        env.observation(out=obs_h)
+    n_pcie = 200
+    clock.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_pcie):
+        env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
+        env.observation(out=obs_h)
+    clock.barrier()
+    el_pcie = time.perf_counter() - t0
+    red, _ = env.reduce_counters()
+    W = env.words_per_link
+    obs_dim = env.obs_dim
+    env.close()
+    A = algorithmic_bytes_per_env_step(topo, W, extra=8 * obs_dim)
+    kernel_ms = float(np.mean(ks)) + float(np.mean(ko))
+    return {"value": B * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": 1,
+            "steps_timed": steps, "timed_region_s": elapsed, "ms_per_step": elapsed * 1e3 / steps,
+            "step_kernel": step_kernel.split(" ")[0], "launch": step_kernel, "observation_kernel": "orlg_deeprmsa_obs_kernel<%d>" % W,
+            "kernel_ms_step": float(np.mean(ks)), "kernel_ms_observation": float(np.mean(ko)), "obs_dim": obs_dim,
+            "pcie_inclusive": {"value": B * n_pcie / el_pcie, "unit": "env steps/s", "ms_per_step": el_pcie * 1e3 / n_pcie,
+                               "what": "deeprmsa_external actions from host memory (4 B/env H2D) + observation copied back to host "
+                                       "memory (%d B/env D2H), pageable numpy buffers, one blocking round trip per step" % (8 * obs_dim)},
+            "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),
+            "roofline": roofline_block("deeprmsa", step_kernel.split(" ")[0] + " + orlg_deeprmsa_obs_kernel<%d>" % W, kernel_ms, A, B, B)}
 
 
 def cpu_baseline(topo, seconds=10.0):
@@ -77,52 +367,29 @@ def cpu_baseline(topo, seconds=10.0):
     return {"value": total / wall, "unit": "env steps/s", "cores": cores, "kind": "port",
             "value_1core": one[0][0] / one[0][1],
             "sample": f"{cores} threads x 1 env each, {total} steps in {wall:.1f} s (+ {one[0][0]} steps on one thread), SAP-FF, "
-                      "same NSFNET-320 load-50 workload, oracle/orlg_oracle.c"}
+                      "same NSFNET-320 load-50 workload, oracle/orlg_oracle.c",
+            "note": "the C oracle is the only CPU restatement timed here: a NumPy restatement of this per-request algorithm is "
+                    "slower than the C one by construction (the reference itself, Python + NumPy, runs 242 env-steps/s on one "
+                    "core: BASELINE.md section 2; it cannot travel to the GPU box)"}
 
 
-def north_star_measurement(topo, args, stream, dev):
-    """BASELINE.json north_star quotes its target (>= 10 M env-steps/s) at batch 65 536 on one MI355X: the same workload at
-    that batch, timed the same way (1 launch of warm-up, 2 timed launches), reported next to the headline.  At this batch
-    the library's AUTO rule runs the four-environments-per-wave step kernel; results are bit-identical."""
-    import torch
-    from optical_rl_gym_amd import BatchedRMSAEnv
-    B2 = 65536
-    env = BatchedRMSAEnv(topo, B2, **ENV_KW, seed=10, stats_level=args.stats, device=dev.index or 0)
-    env.set_stream(stream.cuda_stream)
-    env.run(args.policy, args.chunk, auto_reset=True)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(2):
-        env.run(args.policy, args.chunk, auto_reset=True)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    red, _ = env.reduce_counters()
-    env.close()
-    return {"value": B2 * 2 * args.chunk / dt, "unit": "env steps/s", "batch": B2, "steps": 2 * args.chunk,
-            "ms_per_launch": dt * 1e3 / 2, "step_kernel": "auto -> orlg_rmsa_group_kernel (4 envs per wave)" if args.policy in ("sap_ff", "sp_ff") else "auto",
-            "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / red["services_processed"]}
-
-
+# ------------------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--chunk", type=int, default=1000, help="env steps per kernel launch")
-    ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
-    ap.add_argument("--policy", default="sap_ff")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-north-star", action="store_true", help="skip the extra B=65536 measurement (north_star batch)")
-    ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
-    args = ap.parse_args()
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        return self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import numpy as np
     import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -130,83 +397,36 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
-        torch.cuda.set_device(0)
         local_rank = 0
+        torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
-
-    from conftest import load_topology
-    from optical_rl_gym_amd import BatchedRMSAEnv
-
-    topo_name = MIXED[rank % 3] if args.mixed else TOPOLOGY
-    topo = load_topology(topo_name)
-    B = args.batch
-    from optical_rl_gym_amd.distributed import allreduce_stats, shard_base_seed
-    env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=shard_base_seed(10, B, rank), stats_level=args.stats, device=local_rank)
     # a dedicated (non-default) stream: the step kernels AND the timing events live on it
     stream = torch.cuda.Stream(device=dev)
-    env.set_stream(stream.cuda_stream)
+    clock = Clock(torch, dev, stream, dist)
+    from optical_rl_gym_amd.distributed import allreduce_stats
 
-    def run_steps(k, events=None):
-        left = k
-        while left > 0:
-            n = min(left, args.chunk)
-            if events is not None:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-            env.run(args.policy, n, auto_reset=True)
-            if events is not None:
-                b.record(stream)
-                events.append((a, b, n))
-            left -= n
-
-    def barrier():
-        torch.cuda.synchronize(dev)
+    sub = {}
+    only = args.only
+    out = None
+    if only in (None, "headline", "rmsa_b4096"):
+        B = 4096 if only == "rmsa_b4096" else args.batch
+        topo_name = MIXED[rank % 3] if args.mixed else TOPOLOGY
+        key = "rmsa_b%d" % B
+        rec, vec, elapsed, topo = rmsa_record(clock, topo_name, B, args.chunk, args.warmup, args.steps, args, rank, local_rank, key)
+        # statistics all-reduce (the path's only collective) and the slowest rank's clock
+        stats = allreduce_stats(vec, dist, dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    env.launch_info()  # kernel attributes / occupancy queried once, outside any timing
-    run_steps(args.warmup)
-    events = []
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, events)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # statistics all-reduce (the path's only collective)
-    red, vec = env.reduce_counters()
-    stats = allreduce_stats(vec, dist, dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-
-    if rank == 0:
-        W = env.words_per_link
-        total_steps = B * world * args.steps
-        kernel_ms = [a.elapsed_time(b) for a, b, _ in events]
-        full = [(ms, n) for (ms, (_, _, n)) in zip(kernel_ms, events) if n == args.chunk] or list(zip(kernel_ms, [e[2] for e in events]))
-        avg_ms = float(np.mean([ms for ms, _ in full]))
-        n_per_launch = full[0][1]
-        A = algorithmic_bytes_per_env_step(topo, W)
-        achieved = A * B * n_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch measured with rocprofv3 PMC passes on this workload (profiles/traffic.json), if recorded
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]
-            ent = tj.get(f"rmsa_nsfnet320_B{B}_chunk{n_per_launch}_{args.stats}_{args.policy}")
-            if ent:
-                traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
-        except Exception:
-            pass
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        total_steps = B * world * args.chunk * args.steps
         out = {
             "metric": "env steps/sec (whole node) + blocking-prob parity, NSFNET RMSA 320 slots",
             "value": total_steps / elapsed,
             "unit": "env steps/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": max(1, args.warmup),
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -214,31 +434,48 @@ def main():
             "dtype": "u64 bitmap + f64 statistics",
             "data": "synthetic (reference's Poisson traffic generator run on the device, seeds 10+i)",
             "config": {"workload": (f"RMSA-v0 {'NSFNET/JPN12/US14 (rank mod 3)' if args.mixed else 'NSFNET'} 320 slots load 50, "
-                                    f"batch {B} envs per GPU, {args.policy} on device, "
-                                    f"stats={args.stats}, {args.chunk} env-steps per launch"),
+                                    f"batch {B} envs per GPU, {args.policy} on device, stats={args.stats}; one bench step = one "
+                                    f"launch of {args.chunk} env-steps per env, after {max(1, args.warmup)} warm-up launch(es) of the same shape"),
                        "batch_per_gpu": B, "global_batch": B * world, "policy": args.policy, "stats_level": args.stats,
-                       "chunk": args.chunk, "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src,
-                         "kernel": "orlg_rmsa_kernel_ff<5,%d>" % {"counters": 0, "network": 1, "full": 2}[args.stats],
-                         "kernel_ms_per_launch": avg_ms, "algorithmic_bytes_per_env_step": A,
-                         "env_steps_per_launch": B * n_per_launch},
+                       "env_steps_per_launch_per_env": args.chunk, "parallelism": f"env-shard x{world}"},
+            "timed_region_s": elapsed,
+            "step_kernel": rec["step_kernel"], "launch": rec["launch"],
+            "roofline": rec["roofline"],
             "blocking": {"services_processed": int(stats[0]), "services_accepted": int(stats[1]),
                          "service_blocking_rate": float((stats[0] - stats[1]) / max(1, stats[0])),
                          "bit_rate_blocking_rate": float((stats[4] - stats[5]) / max(1, stats[4])),
                          "episodes_done": int(stats[8]), "num_envs": int(stats[9])},
         }
-        if world == 1 and not args.no_north_star and B != 65536:
-            out["north_star_batch_65536"] = north_star_measurement(topo, args, stream, dev)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(topo)
+        if elapsed < 1.0:
+            out["timed_region_short"] = "timed region below 1 s: raise --steps"
+    if rank == 0 and world == 1 and not args.no_sub_records:
+        jobs = {"rmsa_b4096": lambda: rmsa_record(clock, TOPOLOGY, 4096, args.chunk, 1, 100, args, 0, 0, "rmsa_b4096")[0],
+                "phy_metrics": lambda: phy_record(clock, args, "phy_metrics"),
+                "phy": lambda: phy_record(clock, args, "phy"),
+                "phy_defrag": lambda: phy_record(clock, args, "phy_defrag"),
+                "deeprmsa": lambda: deeprmsa_record(clock, args)}
+        for name, job in jobs.items():
+            if only is None and name == "rmsa_b4096" and args.batch == 4096:
+                continue
+            if only is None or (only == name and name != "rmsa_b4096"):
+                sub[name] = job()
+    if rank == 0:
+        if out is None:   # --only <sub-record>
+            out = {"only": only}
+        if sub:
+            names = {"rmsa_b4096": "rmsa_b4096 (BASELINE configs[1])", "phy_metrics": "phy_us14_b4096 (BASELINE configs[2], with per-step metrics)",
+                     "phy": "phy_us14_b4096_lazy_metrics", "phy_defrag": "phy_us14_b4096_defragmentation",
+                     "deeprmsa": "deeprmsa_b32768 (BASELINE configs[3])"}
+            out["sub_records"] = {names[k]: v for k, v in sub.items()}
+        if world == 1 and not args.no_cpu_baseline and only is None:
+            from conftest import load_topology
+            out["cpu_baseline"] = cpu_baseline(load_topology(TOPOLOGY))
         print(json.dumps(out), flush=True)
-    env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -32,7 +32,10 @@ enum {
     ORLG_ERR_INVALID = -1,     /* bad argument / unsupported size */
     ORLG_ERR_NO_DEVICE = -2,   /* no HIP device or HIP runtime failure */
     ORLG_ERR_HIP = -3,         /* a HIP call failed (message in orlg_last_error) */
-    ORLG_ERR_QUEUE_FULL = -4,  /* an environment's release queue overflowed (raise queue_capacity) */
+    ORLG_ERR_QUEUE_FULL = -4,  /* an environment's release queue (PhyRMSA: also a channel_state list or the defragmentation
+                                * work list) overflowed: the simulation of that environment is no longer the reference's.
+                                * Sticky: reported by every orlg_step / orlg_synchronize / orlg_reduce_counters that waits
+                                * for the stream after the launch that overflowed, until a full reset.  Raise queue_capacity. */
 };
 
 /* Frozen topology: topology.graph["ksp"|"k_paths"|"node_indices"] + edge attr "index"
@@ -145,6 +148,11 @@ int orlg_synchronize(orlg_env *env);
  * out[2] resident workgroups per CU (occupancy query), out[3] 64-bit words per link */
 int orlg_launch_info(orlg_env *env, int32_t *out /* [4] */);
 
+/* name, template arguments and launch shape of the kernel that served the last orlg_step / orlg_reset of this handle, e.g.
+ * "orlg_rmsa_group_kernel<5,2> grid=256 block=704 lds=152064" (for benchmarks and profiles: which of the two step kernels
+ * AUTO picked) */
+int orlg_last_kernel(orlg_env *env, char *buf, int32_t capacity);
+
 /* RMSAEnv.reset(only_episode_counters) (rmsa_env.py:343-457), all envs */
 int orlg_reset(orlg_env *env, int32_t only_episode_counters);
 
@@ -154,6 +162,9 @@ int orlg_reset(orlg_env *env, int32_t only_episode_counters);
  * reset(only_episode_counters=True) to every env whose step returned done. */
 int orlg_step(orlg_env *env, int32_t policy, int32_t n_steps, const int32_t *actions, int32_t auto_reset,
               const orlg_step_io *io);
+/* The launch is asynchronous on the handle's stream.  When host output arrays are given the call waits for them and then
+ * also returns ORLG_ERR_QUEUE_FULL if an environment lost a release; otherwise the next orlg_synchronize /
+ * orlg_reduce_counters reports it. */
 
 /* state read-back (all arrays [B] or [B][...] env-major) */
 int orlg_get_requests(orlg_env *env, orlg_request *out /* [B] */);
@@ -280,6 +291,7 @@ int orlg_phy_reset(orlg_phy_env *env, int32_t only_episode_counters);
  * (the reference's selected_channels tuple fields 0 and 1; used == 0 means the channel's whole capacity). */
 int orlg_phy_step(orlg_phy_env *env, int32_t policy, int32_t n_steps, const int32_t *act_path,
                   const int16_t *act_channels, int32_t auto_reset, const orlg_phy_step_io *io);
+int orlg_phy_last_kernel(orlg_phy_env *env, char *buf, int32_t capacity); /* as orlg_last_kernel */
 int orlg_phy_words_per_link(orlg_phy_env *env);
 int orlg_phy_get_requests(orlg_phy_env *env, orlg_request *out /* [B] */);
 int orlg_phy_get_counters(orlg_phy_env *env, orlg_counters *out /* [B] */);

@@ -100,6 +100,8 @@ def load(build_if_missing=True):
     L.orlg_set_stream.argtypes = [vp, vp]
     L.orlg_synchronize.argtypes = [vp]
     L.orlg_launch_info.argtypes = [vp, vp]
+    L.orlg_last_kernel.argtypes = [vp, C.c_char_p, i32]
+    L.orlg_phy_last_kernel.argtypes = [vp, C.c_char_p, i32]
     L.orlg_reset.argtypes = [vp, i32]
     L.orlg_step.argtypes = [vp, i32, i32, vp, i32, C.POINTER(StepIO)]
     L.orlg_get_requests.argtypes = [vp, vp]
@@ -145,7 +147,7 @@ def load(build_if_missing=True):
 
 EXPORTED_SYMBOLS = [
     "orlg_abi_version", "orlg_last_error", "orlg_device_count", "orlg_create", "orlg_destroy", "orlg_set_stream",
-    "orlg_synchronize", "orlg_launch_info", "orlg_reset", "orlg_step", "orlg_get_requests", "orlg_get_counters",
+    "orlg_synchronize", "orlg_launch_info", "orlg_last_kernel", "orlg_phy_last_kernel", "orlg_reset", "orlg_step", "orlg_get_requests", "orlg_get_counters",
     "orlg_get_current_time", "orlg_get_occupancy", "orlg_words_per_link", "orlg_get_link_stats",
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
     "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",

@@ -34,6 +34,26 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _dtype_name(a):
+    """'int32', 'float64', ... of a numpy array or a torch tensor."""
+    return str(a.dtype).replace("torch.", "")
+
+
+def _check_buffer(name, a, shape, dtype):
+    """A caller-supplied array the library reads or writes through a raw pointer: shape, dtype and layout must be exactly
+    what the C ABI expects (a wrong dtype would be reinterpreted, a short array overrun)."""
+    if tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(a.shape)}, expected {tuple(shape)}")
+    if _dtype_name(a) != str(np.dtype(dtype)):
+        raise TypeError(f"{name}: dtype {_dtype_name(a)}, expected {np.dtype(dtype)}")
+    contiguous = a.is_contiguous() if hasattr(a, "is_contiguous") else a.flags["C_CONTIGUOUS"]
+    if not contiguous:
+        raise ValueError(f"{name}: must be C-contiguous")
+    if not hasattr(a, "data_ptr") and not a.flags["WRITEABLE"] and name.startswith("out"):
+        raise ValueError(f"{name}: read-only array")
+    return a
+
+
 class BatchedRMSAEnv:
     def __init__(self, topology, batch_size: int, *, episode_length: int = 1000, load: float = 10,
                  mean_service_holding_time: float = 10800.0, num_spectrum_resources: int = 100,
@@ -126,6 +146,12 @@ class BatchedRMSAEnv:
     def synchronize(self):
         _lib.check(self.L.orlg_synchronize(self.h))
 
+    def last_kernel(self) -> str:
+        """Name, template arguments and launch shape of the kernel behind the last ``run`` / ``reset``."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.L.orlg_last_kernel(self.h, buf, 128))
+        return buf.value.decode()
+
     def launch_info(self):
         """Launch geometry of the step kernel (envs per workgroup, LDS bytes, resident workgroups per CU)."""
         a = np.zeros(4, np.int32)
@@ -147,17 +173,26 @@ class BatchedRMSAEnv:
         res = {}
         names = list(outputs) + [k for k in (out or {}) if k not in outputs]
         for name in names:
+            if name not in _lib.STEP_IO_DTYPES:
+                raise KeyError(f"unknown step output {name!r}")
+            shape = (n_steps, B, 4) if name == "request" else (n_steps, B)
             if out is not None and name in out:
-                arr = out[name]
+                arr = _check_buffer(f"out[{name!r}]", out[name], shape, _lib.STEP_IO_DTYPES[name])
             else:
-                shape = (n_steps, B, 4) if name == "request" else (n_steps, B)
                 arr = np.zeros(shape, dtype=_lib.STEP_IO_DTYPES[name])
             res[name] = arr
             setattr(io, name, _ptr(arr))
         ap = None
-        if actions is not None:
+        if policy in ("external", "deeprmsa_external", "path_ff_external"):
+            if actions is None:
+                raise ValueError(f"policy {policy!r} needs an actions array")
+            ashape = (B, 2) if policy == "external" else (B,)
             if not hasattr(actions, "data_ptr"):
+                actions = np.asarray(actions)
+                if actions.dtype.kind not in "iu":
+                    raise TypeError(f"actions: dtype {actions.dtype}, expected an integer type")
                 actions = np.ascontiguousarray(actions, dtype=np.int32)
+            _check_buffer("actions", actions, ashape, np.int32)
             ap = _ptr(actions)
         _lib.check(self.L.orlg_step(self.h, _lib.POLICIES[policy], int(n_steps), ap, 1 if auto_reset else 0,
                                     C.byref(io)))
@@ -246,6 +281,8 @@ class BatchedRMSAEnv:
         """DeepRMSAEnv.observation() for every env: [B, obs_dim] float64."""
         if out is None:
             out = np.zeros((self.batch_size, self.obs_dim), np.float64)
+        else:
+            _check_buffer("out", out, (self.batch_size, self.obs_dim), np.float64)
         _lib.check(self.L.orlg_deeprmsa_observation(self.h, _ptr(out)))
         return out
 
@@ -254,6 +291,8 @@ class BatchedRMSAEnv:
         dim = self.L.orlg_simple_matrix_obs_dim(self.h)
         if out is None:
             out = np.zeros((self.batch_size, dim), np.uint8)
+        else:
+            _check_buffer("out", out, (self.batch_size, dim), np.uint8)
         _lib.check(self.L.orlg_simple_matrix_observation(self.h, _ptr(out)))
         return out
 

@@ -2,23 +2,12 @@
 // Owns the device state of B environments, builds the read-only tables, seeds MT19937 the way
 // random.Random(int) does and launches the kernels of orlg_kernels.hip.  No CPU compute path exists:
 // every entry point that touches environments needs a HIP device.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/orlg.h"
-#include "orlg_kernels.hip"
-#include "orlg_group_kernels.hip"
+#include "orlg_host.h"
+#include "orlg_kernels.hip"   // data layout + device helpers; the step kernels are instantiated in orlg_inst_*.hip
 
 // ---------------------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...) {
+int orlg_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -27,11 +16,22 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(ORLG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+
+int orlg_err_word_create(OrlgErrWord *w) {
+    void *h = nullptr, *d = nullptr;
+    w->host = nullptr; w->dev = nullptr;
+    HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    memset(h, 0, 64);
+    hipError_t er = hipHostGetDevicePointer(&d, h, 0);
+    if (er != hipSuccess) { (void)hipHostFree(h); return fail(ORLG_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(er)); }
+    w->host = static_cast<volatile int32_t *>(h);
+    w->dev = static_cast<int32_t *>(d);
+    return ORLG_OK;
+}
+void orlg_err_word_destroy(OrlgErrWord *w) {
+    if (w->host) (void)hipHostFree(const_cast<int32_t *>(w->host));
+    w->host = nullptr; w->dev = nullptr;
+}
 
 // ---------------------------------------------------------------------------------------- handle
 struct orlg_env {
@@ -60,7 +60,19 @@ struct orlg_env {
     size_t io_cap[12];
     int32_t *d_actions;
     size_t d_actions_cap;
+    OrlgErrWord err;         // sticky error word the kernels set on a release-queue overflow
+    char last_kernel[96];    // name and shape of the kernel behind the last step / reset launch (orlg_last_kernel)
 };
+
+// wait for the handle's stream, then report an overflow a kernel flagged (ORLG_ERR_QUEUE_FULL is sticky until a full reset)
+static int sync_check(orlg_env *e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->err.host && *e->err.host)
+        return fail(ORLG_ERR_QUEUE_FULL, "a release queue overflowed (capacity %d): the service stays provisioned and is never "
+                                         "released -- raise queue_capacity", e->p.Q);
+    return ORLG_OK;
+}
+#define SYNC_CHECK(e) do { int rc_ = sync_check(e); if (rc_) return rc_; } while (0)
 
 template <typename T>
 static int dev_alloc(orlg_env *e, T **out, size_t count) {
@@ -80,7 +92,7 @@ static int dev_upload(orlg_env *e, T **out, const T *host, size_t count) {
 
 // ---------------------------------------------------------------------------------------- MT19937 seeding
 // CPython _randommodule.c: random.Random(n) -> init_by_array(32-bit little-endian chunks of abs(n)).
-static void mt_seed(uint32_t *mt, uint64_t seed) {
+void orlg_mt_seed(uint32_t *mt, uint64_t seed) {
     uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
     int len = key[1] ? 2 : 1;
     mt[0] = 19650218u;
@@ -122,6 +134,49 @@ __global__ void orlg_clear_state_kernel(OrlgParams p, int W, int keep_rng) {
         s.ring_cnt = keep_rng ? p.scal[i].ring_cnt : 0;
         p.scal[i] = s;
     }
+}
+
+// SimpleMatrixObservation.observation (rmsa_env.py:952-971) for every env: [B][2N + E*S] uint8 = one-hot of the lower
+// and of the higher endpoint index, then the free-slot flags link-major (the bitmap unpacked).
+__global__ __launch_bounds__(256) void orlg_simple_matrix_obs_kernel(const OrlgParams p, int W, uint8_t *out) {
+    const size_t dim = (size_t)2 * p.N + (size_t)p.E * p.S;
+    const size_t total = dim * p.B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / dim, q = i - b * dim;
+        uint8_t v;
+        if (q < (size_t)2 * p.N) {
+            const OrlgEnvScalars *sc = p.scal + b;
+            const int mn = sc->req_src < sc->req_dst ? sc->req_src : sc->req_dst;
+            const int mx = sc->req_src < sc->req_dst ? sc->req_dst : sc->req_src;
+            v = ((int)q == mn || (int)q == p.N + mx) ? 1 : 0;
+        } else {
+            const size_t r = q - 2 * p.N;
+            const int link = (int)(r / p.S), s = (int)(r - (size_t)link * p.S);
+            v = (uint8_t)((p.occ[b * p.NW + (size_t)link * W + (s >> 6)] >> (s & 63)) & 1ull);
+        }
+        out[i] = v;
+    }
+}
+
+// Sum of the counters of all envs (one workgroup; 64-bit integer adds, deterministic order per lane
+// then a fixed tree): the vector the multi-GPU layer all-reduces.
+__global__ __launch_bounds__(256) void orlg_reduce_counters_kernel(const OrlgEnvScalars *scal, int B, long long *out) {
+    __shared__ long long part[256][10];
+    long long acc[10];
+    for (int q = 0; q < 10; ++q) acc[q] = 0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        for (int q = 0; q < 8; ++q) acc[q] += scal[i].c[q];
+        acc[8] += scal[i].episodes_done;
+        acc[9] += 1;
+    }
+    for (int q = 0; q < 10; ++q) part[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 10; ++q) part[threadIdx.x][q] += part[threadIdx.x + s][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x < 10 ? part[0][threadIdx.x] : 0;
 }
 
 enum { EX_REQUEST, EX_COUNTERS, EX_TIME, EX_GRAPH, EX_RUNNING, EX_EPISODES, EX_HIST, EX_LSTAT };
@@ -177,90 +232,34 @@ __global__ void orlg_overflow_kernel(const OrlgEnvScalars *scal, int B, int *out
 }
 
 // ---------------------------------------------------------------------------------------- kernel dispatch
-typedef void (*rmsa_kernel_t)(const OrlgParams);
-template <int W>
-static rmsa_kernel_t pick_stats(int stats, bool step) {
-    switch (stats) {
-        case 0: return step ? orlg_rmsa_kernel<W, 0> : orlg_rmsa_reset_kernel<W, 0>;
-        case 1: return step ? orlg_rmsa_kernel<W, 1> : orlg_rmsa_reset_kernel<W, 1>;
-        default: return step ? orlg_rmsa_kernel<W, 2> : orlg_rmsa_reset_kernel<W, 2>;
-    }
-}
-template <int W>
-static rmsa_kernel_t pick_ff_stats(int stats) {
-    switch (stats) {
-        case 0: return orlg_rmsa_kernel_ff<W, 0>;
-        case 1: return orlg_rmsa_kernel_ff<W, 1>;
-        default: return orlg_rmsa_kernel_ff<W, 2>;
+// the kernels live in per-W objects (orlg_inst_wave.hip / orlg_inst_group.hip); a W the library was not built for is a null symbol
+typedef orlg_rmsa_kernel_t rmsa_kernel_t;
+typedef orlg_masks_kernel_t masks_kernel_t;
+static rmsa_kernel_t pick_wave(int W, int kind, int stats) {
+    switch (W) {
+#define X(n) case n: return orlg_wave_kernel_W##n ? orlg_wave_kernel_W##n(kind, stats) : nullptr;
+        ORLG_FOR_EACH_W(X)
+#undef X
+        default: return nullptr;
     }
 }
 // the wave-per-environment step kernel that only carries the first-fit policies (k <= 8)
-static rmsa_kernel_t pick_rmsa_ff(int W, int stats) {
-    switch (W) {
-        case 1: return pick_ff_stats<1>(stats);
-        case 2: return pick_ff_stats<2>(stats);
-        case 3: return pick_ff_stats<3>(stats);
-        case 4: return pick_ff_stats<4>(stats);
-        case 5: return pick_ff_stats<5>(stats);
-        case 6: return pick_ff_stats<6>(stats);
-        case 8: return pick_ff_stats<8>(stats);
-        default: return nullptr;
-    }
-}
-static rmsa_kernel_t pick_rmsa(int W, int stats, bool step = true) {
-    switch (W) {
-        case 1: return pick_stats<1>(stats, step);
-        case 2: return pick_stats<2>(stats, step);
-        case 3: return pick_stats<3>(stats, step);
-        case 4: return pick_stats<4>(stats, step);
-        case 5: return pick_stats<5>(stats, step);
-        case 6: return pick_stats<6>(stats, step);
-        case 8: return pick_stats<8>(stats, step);
-        default: return nullptr;
-    }
-}
-template <int W>
-static rmsa_kernel_t pick_group_stats(int stats) {
-    switch (stats) {
-        case 0: return orlg_rmsa_group_kernel<W, 0>;
-        case 1: return orlg_rmsa_group_kernel<W, 1>;
-        default: return orlg_rmsa_group_kernel<W, 2>;
-    }
-}
+static rmsa_kernel_t pick_rmsa_ff(int W, int stats) { return pick_wave(W, ORLG_KIND_STEP_FF, stats); }
+static rmsa_kernel_t pick_rmsa(int W, int stats, bool step = true) { return pick_wave(W, step ? ORLG_KIND_STEP : ORLG_KIND_RESET, stats); }
+static rmsa_kernel_t pick_obs(int W) { return pick_wave(W, ORLG_KIND_OBS, 0); }
 static rmsa_kernel_t pick_group(int W, int stats) {
     switch (W) {
-        case 1: return pick_group_stats<1>(stats);
-        case 2: return pick_group_stats<2>(stats);
-        case 3: return pick_group_stats<3>(stats);
-        case 4: return pick_group_stats<4>(stats);
-        case 5: return pick_group_stats<5>(stats);
-        case 6: return pick_group_stats<6>(stats);
-        case 8: return pick_group_stats<8>(stats);
+#define X(n) case n: return orlg_group_kernel_W##n ? orlg_group_kernel_W##n(stats) : nullptr;
+        ORLG_FOR_EACH_W(X)
+#undef X
         default: return nullptr;
     }
 }
-static rmsa_kernel_t pick_obs(int W) {
-    switch (W) {
-        case 1: return orlg_deeprmsa_obs_kernel<1>;
-        case 2: return orlg_deeprmsa_obs_kernel<2>;
-        case 3: return orlg_deeprmsa_obs_kernel<3>;
-        case 4: return orlg_deeprmsa_obs_kernel<4>;
-        case 5: return orlg_deeprmsa_obs_kernel<5>;
-        case 6: return orlg_deeprmsa_obs_kernel<6>;
-        case 8: return orlg_deeprmsa_obs_kernel<8>;
-        default: return nullptr;
-    }
-}
-typedef void (*masks_kernel_t)(const OrlgParams, int, int, int, u64 *, int32_t *);
 static masks_kernel_t pick_masks(int W) {
     switch (W) {
-        case 1: return orlg_path_masks_kernel<1>;
-        case 2: return orlg_path_masks_kernel<2>;
-        case 3: return orlg_path_masks_kernel<3>;
-        case 4: return orlg_path_masks_kernel<4>;
-        case 5: return orlg_path_masks_kernel<5>;
-        case 6: return orlg_path_masks_kernel<6>;
-        case 8: return orlg_path_masks_kernel<8>;
+#define X(n) case n: return orlg_masks_kernel_W##n ? orlg_masks_kernel_W##n() : nullptr;
+        ORLG_FOR_EACH_W(X)
+#undef X
         default: return nullptr;
     }
 }
@@ -299,6 +298,8 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d> grid=%d block=%d lds=%zu", e->W, p.stats_level,
+             nblocks, ORLG_WAVE * wpb, lds_bytes);
     return ORLG_OK;
 }
 
@@ -338,10 +339,13 @@ static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "%s<%d,%d> grid=%d block=%d lds=%zu",
+             ff ? "orlg_rmsa_kernel_ff" : (p.mode == ORLG_MODE_STEP ? "orlg_rmsa_kernel" : "orlg_rmsa_reset_kernel"), e->W, p.stats_level,
+             nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 
-static int is_device_ptr(const void *ptr) {
+int orlg_is_device_ptr(const void *ptr) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
         (void)hipGetLastError();
@@ -399,6 +403,7 @@ int orlg_destroy(orlg_env *e) {
     for (int i = 0; i < 12; i++)
         if (e->io_buf[i]) (void)hipFree(e->io_buf[i]);
     if (e->d_actions) (void)hipFree(e->d_actions);
+    orlg_err_word_destroy(&e->err);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return ORLG_OK;
@@ -442,11 +447,17 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         e->num_cu = er == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     e->d_actions = nullptr; e->d_actions_cap = 0; e->num_paths = t->num_paths;
+    e->err.host = nullptr; e->err.dev = nullptr; e->last_kernel[0] = 0;
     for (int i = 0; i < 12; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
 
+    {
+        int rc0 = orlg_err_word_create(&e->err);
+        if (rc0) { orlg_destroy(e); return rc0; }
+    }
     OrlgParams &p = e->p;
+    p.err_flag = e->err.dev;
     p.B = batch; p.N = N; p.E = E; p.S = S; p.K = K; p.NBR = NBR; p.NW = E * W;
     p.episode_length = c->episode_length; p.reward_mode = c->reward_mode; p.stats_level = c->stats_level; p.j = c->j;
     p.obs_dim = 1 + 2 * N + (2 * c->j + 3) * K;
@@ -611,7 +622,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     TRY(dev_alloc(e, &p.ring_req, (size_t)batch * ORLG_RING));
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
-        for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+        for (int i = 0; i < batch; i++) orlg_mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
         hipError_t er = hipMemcpy(p.mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (er != hipSuccess) { orlg_destroy(e); return fail(ORLG_ERR_HIP, "upload of MT19937 states: %s", hipGetErrorString(er)); }
     }
@@ -643,6 +654,12 @@ int orlg_launch_info(orlg_env *e, int32_t *out) {
     return ORLG_OK;
 }
 
+int orlg_last_kernel(orlg_env *e, char *buf, int32_t cap) {
+    if (!e || !buf || cap < 1) return fail(ORLG_ERR_INVALID, "null argument");
+    snprintf(buf, (size_t)cap, "%s", e->last_kernel);
+    return ORLG_OK;
+}
+
 int orlg_set_stream(orlg_env *e, void *hip_stream) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(e->device));
@@ -660,7 +677,7 @@ int orlg_set_stream(orlg_env *e, void *hip_stream) {
 int orlg_synchronize(orlg_env *e) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    SYNC_CHECK(e);
     return ORLG_OK;
 }
 
@@ -672,6 +689,8 @@ int orlg_reset(orlg_env *e, int32_t only_episode_counters) {
     if (only_episode_counters) {
         p.mode = ORLG_MODE_EPISODE_RESET;
     } else {
+        HIP_TRY(hipStreamSynchronize(e->stream));   // a full reset also clears a reported queue overflow
+        *e->err.host = 0;
         hipLaunchKernelGGL(orlg_clear_state_kernel, dim3(512), dim3(256), 0, e->stream, e->p, e->W, 1);
         HIP_TRY(hipGetLastError());
         p.mode = ORLG_MODE_INIT;
@@ -694,7 +713,7 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
     p.mode = ORLG_MODE_STEP; p.n_steps = n_steps; p.policy = policy; p.auto_reset = auto_reset;
     if (ext) {
         size_t n = (size_t)p.B * (policy == ORLG_POLICY_EXTERNAL ? 2 : 1);
-        if (is_device_ptr(actions)) {
+        if (orlg_is_device_ptr(actions)) {
             p.actions = actions;
         } else {
             if (n > e->d_actions_cap) {
@@ -722,7 +741,7 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
         p.outs[i] = nullptr;
         if (!slots[i].user) continue;
         p.out_mask |= 1 << i;
-        if (is_device_ptr(slots[i].user)) {
+        if (orlg_is_device_ptr(slots[i].user)) {
             p.outs[i] = slots[i].user;
         } else {
             size_t bytes = cnt * slots[i].elem;
@@ -744,7 +763,7 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
             HIP_TRY(hipMemcpyAsync(slots[i].user, e->io_buf[i], cnt * slots[i].elem, hipMemcpyDeviceToHost, e->stream));
             any = true;
         }
-    if (any) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (any) SYNC_CHECK(e);
     return ORLG_OK;
 }
 
@@ -863,7 +882,7 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
     HIP_TRY(hipSetDevice(e->device));
     OrlgParams p = e->p;
     size_t bytes = (size_t)p.B * p.obs_dim * 8;
-    const bool dev = is_device_ptr(out);
+    const bool dev = orlg_is_device_ptr(out);
     if (!dev) {
         int rc = ensure_staging(e, bytes);
         if (rc) return rc;
@@ -890,7 +909,7 @@ int orlg_simple_matrix_observation(orlg_env *e, uint8_t *out) {
     if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->p.B * (size_t)(2 * e->p.N + e->p.E * e->p.S);
-    const bool dev = is_device_ptr(out);
+    const bool dev = orlg_is_device_ptr(out);
     uint8_t *d = out;
     if (!dev) {
         int rc = ensure_staging(e, bytes);
@@ -917,7 +936,7 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
     int hflag = 0;
     HIP_TRY(hipMemcpyAsync(&hflag, flag, 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(out, d, 16 * 8, hipMemcpyDefault, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    SYNC_CHECK(e);
     if (hflag) return fail(ORLG_ERR_QUEUE_FULL, "a release queue overflowed (capacity %d): raise queue_capacity", e->p.Q);
     return ORLG_OK;
 }
@@ -926,7 +945,7 @@ int orlg_reduce_counters(orlg_env *e, int64_t *out) {
 
 // ---------------------------------------------------------------------------------------- checkpoint / resume
 // The whole simulation state of a handle is a handful of flat device arrays: a snapshot is their concatenation.
-struct StatePart { void *ptr; size_t bytes; };
+typedef OrlgStatePart StatePart;
 static std::vector<StatePart> rmsa_state_parts(orlg_env *e) {
     const OrlgParams &p = e->p;
     const size_t B = p.B;
@@ -935,7 +954,7 @@ static std::vector<StatePart> rmsa_state_parts(orlg_env *e) {
             {p.lstat, B * 4 * p.E * 8}, {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8},
             {p.ring_req, B * ORLG_RING * 4}};
 }
-static int state_copy(const std::vector<StatePart> &parts, void *buffer, bool save, int device, hipStream_t stream) {
+int orlg_state_copy(const std::vector<OrlgStatePart> &parts, void *buffer, bool save, int device, hipStream_t stream) {
     HIP_TRY(hipSetDevice(device));
     unsigned char *b = static_cast<unsigned char *>(buffer);
     for (const StatePart &sp : parts) {
@@ -955,11 +974,11 @@ int64_t orlg_state_size(orlg_env *e) {
 }
 int orlg_save_state(orlg_env *e, void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return state_copy(rmsa_state_parts(e), buffer, true, e->device, e->stream);
+    return orlg_state_copy(rmsa_state_parts(e), buffer, true, e->device, e->stream);
 }
 int orlg_load_state(orlg_env *e, const void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return state_copy(rmsa_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    return orlg_state_copy(rmsa_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
 }
 }
 
@@ -982,5 +1001,3 @@ extern "C" int orlg_debug_sections(unsigned long long *out, int reset) {
     return ORLG_OK;
 }
 #endif
-#include "orlg_phy_api.hip"
-#include "orlg_osnr.hip"

@@ -12,6 +12,9 @@
 #define ORLG_NSLOT_STRIDE 8   // nslots table: [bit-rate index][spectral efficiency 0..7]
 #define ORLG_NUM_OUTS 12
 #define ORLG_RING 64           // arrivals generated per refill (one per lane)
+#ifndef ORLG_GROUP_WAVES
+#define ORLG_GROUP_WAVES 12    // four-environments-per-wave kernel: waves per workgroup at most (LDS decides how many fit): up to 3 per SIMD
+#endif
 #define ORLG_DIRECT_STEPS 4    // launches of at most this many steps read their ring entries straight from HBM
 
 // One k-shortest-path record (16 B): Path.hops, Path.best_modulation.spectral_efficiency and the link
@@ -96,6 +99,7 @@ struct OrlgParams {
     const int32_t *actions;
     void *outs[ORLG_NUM_OUTS];
     double *o_obs;
+    int32_t *err_flag;        // the handle's sticky error word (mapped host memory): 1 = a release queue overflowed
     // work queue: every wave draws environments from *ticket until the launch's B are taken (ticket - ticket_base
     // is the environment index; the host advances ticket_base by B + launched waves per launch, no memset needed)
     uint32_t *ticket;

@@ -203,9 +203,6 @@ DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
 }
 
 template <int W, int STATS>
-#ifndef ORLG_GROUP_WAVES
-#define ORLG_GROUP_WAVES 12  // waves per workgroup at most (LDS decides how many fit): up to 3 per SIMD
-#endif
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3) / 4) void orlg_rmsa_group_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
@@ -622,6 +619,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = q_overflow;
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
             go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
+            if (q_overflow) *p.err_flag = 1;   // reported by the next entry point that waits for the stream
         }
     }
     wave_sync();

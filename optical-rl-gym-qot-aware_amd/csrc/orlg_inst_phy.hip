@@ -1,0 +1,12 @@
+// orlg_inst_phy.hip -- instantiation of the QoT-aware step kernel (orlg_phy_kernels.hip) for ONE word count,
+// -DORLG_INST_W=<W> (see orlg_inst_wave.hip).
+#include "orlg_host.h"
+#include "orlg_phy_kernels.hip"
+
+#ifndef ORLG_INST_W
+#error "compile with -DORLG_INST_W=<words per link>"
+#endif
+#define ORLG_CAT2(a, b) a##b
+#define ORLG_CAT(a, b) ORLG_CAT2(a, b)
+
+orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)() { return orlg_phy_kernel<ORLG_INST_W>; }

@@ -707,7 +707,12 @@ __device__ unsigned long long orlg_sections[16];
 #define SEC(i) do { const long long sec_n = __builtin_readcyclecounter(); if (lane == 0) sec_acc[wib][sec_cur] += (unsigned long long)(sec_n - sec_t0); \
     sec_t0 = sec_n; sec_cur = (i); } while (0)
 #define SEC_FLUSH do { SEC(0); wave_sync(); if (lane < 16) atomicAdd(&orlg_sections[lane], sec_acc[wib][lane]); } while (0)
+// device functions that time their own sub-sections take the kernel's accumulators along
+#define SEC_PARAMS , unsigned long long (*sec_acc)[16], long long &sec_t0, int &sec_cur, int wib
+#define SEC_ARGS , sec_acc, sec_t0, sec_cur, wib
 #else
+#define SEC_PARAMS
+#define SEC_ARGS
 #define SEC_DECL
 #define SEC_DECL_G
 #define SEC(i) do { } while (0)
@@ -1208,6 +1213,7 @@ DEV void rmsa_body(const OrlgParams &p) {
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
             go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
+            if (ws->q_overflow) *kp->err_flag = 1;   // reported by the next entry point that waits for the stream
         }
         wave_sync();
         if (lane < (int)sizeof(OrlgEnvScalars) / 16)
@@ -1401,47 +1407,4 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
         }
         wave_sync();
     }
-}
-
-// SimpleMatrixObservation.observation (rmsa_env.py:952-971) for every env: [B][2N + E*S] uint8 = one-hot of the lower
-// and of the higher endpoint index, then the free-slot flags link-major (the bitmap unpacked).
-__global__ __launch_bounds__(256) void orlg_simple_matrix_obs_kernel(const OrlgParams p, int W, uint8_t *out) {
-    const size_t dim = (size_t)2 * p.N + (size_t)p.E * p.S;
-    const size_t total = dim * p.B;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / dim, q = i - b * dim;
-        uint8_t v;
-        if (q < (size_t)2 * p.N) {
-            const OrlgEnvScalars *sc = p.scal + b;
-            const int mn = sc->req_src < sc->req_dst ? sc->req_src : sc->req_dst;
-            const int mx = sc->req_src < sc->req_dst ? sc->req_dst : sc->req_src;
-            v = ((int)q == mn || (int)q == p.N + mx) ? 1 : 0;
-        } else {
-            const size_t r = q - 2 * p.N;
-            const int link = (int)(r / p.S), s = (int)(r - (size_t)link * p.S);
-            v = (uint8_t)((p.occ[b * p.NW + (size_t)link * W + (s >> 6)] >> (s & 63)) & 1ull);
-        }
-        out[i] = v;
-    }
-}
-
-// Sum of the counters of all envs (one workgroup; 64-bit integer adds, deterministic order per lane
-// then a fixed tree): the vector the multi-GPU layer all-reduces.
-__global__ __launch_bounds__(256) void orlg_reduce_counters_kernel(const OrlgEnvScalars *scal, int B, long long *out) {
-    __shared__ long long part[256][10];
-    long long acc[10];
-    for (int q = 0; q < 10; ++q) acc[q] = 0;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        for (int q = 0; q < 8; ++q) acc[q] += scal[i].c[q];
-        acc[8] += scal[i].episodes_done;
-        acc[9] += 1;
-    }
-    for (int q = 0; q < 10; ++q) part[threadIdx.x][q] = acc[q];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int q = 0; q < 10; ++q) part[threadIdx.x][q] += part[threadIdx.x + s][q];
-        __syncthreads();
-    }
-    if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x < 10 ? part[0][threadIdx.x] : 0;
 }

@@ -1,5 +1,5 @@
 // orlg_osnr.hip -- GN-model GSNR admission check (examples/calculate_osnr.py:9-56) as a HIP kernel + its C entry point.
-// Included at the end of orlg_api.hip.  One wavefront per admission check; lanes run over the interferers of a link.
+// Its own translation unit.  One wavefront per admission check; lanes run over the interferers of a link.
 //
 // The reference routine is sequential and carries a quirk that is reproduced here: `sum_phi += phi` also executes for
 // the list entry that IS the current service, adding the stale `phi` of the entry visited before it (the previous
@@ -7,7 +7,7 @@
 // initially 0) -- calculate_osnr.py:16,31-46.  The lane-parallel sum adds the same terms in a different order, which
 // moves the result by a few 1e-16 relative (north_star tolerance: 1e-6 relative).  PARITY UNPINNED by the reference
 // (no caller, no test, not importable: SURVEY 0.3 / 8c); checked against tests/golden/osnr_grid.npz and the oracle.
-#pragma once
+#include "orlg_host.h"
 #include "orlg_kernels.hip"
 
 struct OrlgOsnrDev {
@@ -146,7 +146,7 @@ extern "C" int orlg_gn_osnr(const orlg_osnr_batch *q, double *gsnr_db, int32_t d
     std::vector<void *> tmp;
     auto cleanup = [&]() { for (void *t : tmp) (void)hipFree(t); };
     auto on_device = [&](const void *ptr, size_t bytes, const void **out) -> int {
-        if (bytes == 0 || is_device_ptr(ptr)) { *out = ptr; return ORLG_OK; }
+        if (bytes == 0 || orlg_is_device_ptr(ptr)) { *out = ptr; return ORLG_OK; }
         void *d = nullptr;
         hipError_t er = hipMalloc(&d, bytes);
         if (er != hipSuccess) return fail(ORLG_ERR_HIP, "hipMalloc: %s", hipGetErrorString(er));
@@ -170,7 +170,7 @@ extern "C" int orlg_gn_osnr(const orlg_osnr_batch *q, double *gsnr_db, int32_t d
 #undef ONDEV
     if (rc) { cleanup(); return rc; }
     double *d_out = gsnr_db;
-    const bool out_dev = is_device_ptr(gsnr_db);
+    const bool out_dev = orlg_is_device_ptr(gsnr_db);
     if (!out_dev) {
         void *d = nullptr;
         hipError_t er = hipMalloc(&d, M * 8);

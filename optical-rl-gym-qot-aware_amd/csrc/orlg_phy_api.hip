@@ -1,6 +1,7 @@
 // orlg_phy_api.hip -- host side of the QoT-aware (PhyRMSA) path: orlg_phy_* entry points of include/orlg.h.
-// Included at the end of orlg_api.hip (one translation unit; shares its helpers).
-#include "orlg_phy_kernels.hip"
+// Its own translation unit; the step kernel is instantiated per word count in orlg_inst_phy.hip.
+#include "orlg_host.h"
+#include "orlg_phy_kernels.hip"   // data layout + device helpers
 
 struct orlg_phy_env {
     OrlgPhyParams p;
@@ -16,16 +17,24 @@ struct orlg_phy_env {
     size_t io_cap[ORLG_PHY_NUM_OUTS];
     int32_t *d_act_path;
     int16_t *d_act_ch;
+    OrlgErrWord err;         // sticky error word the kernel sets when a queue / channel_state list / work list overflows
+    char last_kernel[96];    // name and shape of the kernel behind the last launch (orlg_phy_last_kernel)
 };
 
-typedef void (*phy_kernel_t)(const OrlgPhyParams);
+static int phy_sync_check(orlg_phy_env *e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->err.host && *e->err.host)
+        return fail(ORLG_ERR_QUEUE_FULL, "a release queue, channel_state list or defragmentation work list overflowed: raise "
+                                         "queue_capacity / channel_state_capacity / defrag_capacity");
+    return ORLG_OK;
+}
+
+typedef orlg_phy_kernel_t phy_kernel_t;
 static phy_kernel_t pick_phy(int W) {
     switch (W) {
-        case 1: return orlg_phy_kernel<1>;
-        case 2: return orlg_phy_kernel<2>;
-        case 3: return orlg_phy_kernel<3>;
-        case 4: return orlg_phy_kernel<4>;
-        case 5: return orlg_phy_kernel<5>;
+#define X(n) case n: return orlg_phy_kernel_W##n ? orlg_phy_kernel_W##n() : nullptr;
+        ORLG_FOR_EACH_PHY_W(X)
+#undef X
         default: return nullptr;
     }
 }
@@ -119,6 +128,8 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d> grid=%d block=%d lds=%zu", e->W, nblocks, ORLG_WAVE * wpb,
+             e->lds_block_bytes);
     return ORLG_OK;
 }
 
@@ -148,6 +159,7 @@ int orlg_phy_destroy(orlg_phy_env *e) {
         if (e->io_buf[i]) (void)hipFree(e->io_buf[i]);
     if (e->d_act_path) (void)hipFree(e->d_act_path);
     if (e->d_act_ch) (void)hipFree(e->d_act_ch);
+    orlg_err_word_destroy(&e->err);
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return ORLG_OK;
@@ -192,11 +204,17 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     memset(&e->p, 0, sizeof(e->p));
     e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
     e->d_act_path = nullptr; e->d_act_ch = nullptr; e->num_paths = t->num_paths;
+    e->err.host = nullptr; e->err.dev = nullptr; e->last_kernel[0] = 0;
     e->resident_blocks = 0; e->ticket_base = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
+    {
+        int rc0 = orlg_err_word_create(&e->err);
+        if (rc0) { orlg_phy_destroy(e); return rc0; }
+    }
     OrlgPhyParams &p = e->p;
+    p.err_flag = e->err.dev;
     p.B = batch; p.N = N; p.E = E; p.C = C; p.K = K; p.NBR = NBR; p.NW = E * W;
     p.episode_length = c->episode_length; p.num_rows = c->num_table_rows; p.cpad = W * 64;
     p.arrival_lambda = c->arrival_lambda; p.holding_lambda = c->holding_lambda;
@@ -376,7 +394,7 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     }
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
-        for (int i = 0; i < batch; i++) mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+        for (int i = 0; i < batch; i++) orlg_mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
         hipError_t er = hipMemcpy(p.mt, mt.data(), mt.size() * 4, hipMemcpyHostToDevice);
         if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "upload of MT19937 states: %s", hipGetErrorString(er)); }
     }
@@ -415,6 +433,8 @@ int orlg_phy_reset(orlg_phy_env *e, int32_t only_episode_counters) {
     if (only_episode_counters) {
         p.mode = ORLG_MODE_EPISODE_RESET;
     } else {
+        HIP_TRY(hipStreamSynchronize(e->stream));   // a full reset also clears a reported overflow
+        *e->err.host = 0;
         hipLaunchKernelGGL(orlg_phy_clear_kernel, dim3(512), dim3(256), 0, e->stream, e->p, e->W, 1);
         HIP_TRY(hipGetLastError());
         p.mode = ORLG_MODE_INIT;
@@ -433,7 +453,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
     OrlgPhyParams p = e->p;
     p.mode = ORLG_MODE_STEP; p.n_steps = n_steps; p.policy = policy; p.auto_reset = auto_reset;
     if (policy == ORLG_PHY_POLICY_EXTERNAL) {
-        if (is_device_ptr(act_path) && is_device_ptr(act_channels)) {
+        if (orlg_is_device_ptr(act_path) && orlg_is_device_ptr(act_channels)) {
             p.act_path = act_path; p.act_channels = act_channels;
         } else {
             if (!e->d_act_path) {
@@ -459,7 +479,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
         p.outs[i] = nullptr;
         if (!slots[i].user) continue;
         p.out_mask |= 1 << i;
-        if (is_device_ptr(slots[i].user)) {
+        if (orlg_is_device_ptr(slots[i].user)) {
             p.outs[i] = slots[i].user;
         } else {
             size_t bytes = cnt * slots[i].elem;
@@ -481,14 +501,19 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
             HIP_TRY(hipMemcpyAsync(slots[i].user, e->io_buf[i], cnt * slots[i].elem, hipMemcpyDeviceToHost, e->stream));
             any = true;
         }
-    if (any) HIP_TRY(hipStreamSynchronize(e->stream));
+    if (any) return phy_sync_check(e);
     return ORLG_OK;
 }
 
 int orlg_phy_synchronize(orlg_phy_env *e) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    return phy_sync_check(e);
+}
+
+int orlg_phy_last_kernel(orlg_phy_env *e, char *buf, int32_t cap) {
+    if (!e || !buf || cap < 1) return fail(ORLG_ERR_INVALID, "null argument");
+    snprintf(buf, (size_t)cap, "%s", e->last_kernel);
     return ORLG_OK;
 }
 int orlg_phy_words_per_link(orlg_phy_env *e) { return e ? e->W : ORLG_ERR_INVALID; }
@@ -524,6 +549,7 @@ int orlg_phy_get_occupancy(orlg_phy_env *e, uint64_t *out) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     return ORLG_OK;
 }
+typedef OrlgStatePart StatePart;
 static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
     const OrlgPhyParams &p = e->p;
     const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
@@ -538,11 +564,11 @@ int64_t orlg_phy_state_size(orlg_phy_env *e) {
 }
 int orlg_phy_save_state(orlg_phy_env *e, void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return state_copy(phy_state_parts(e), buffer, true, e->device, e->stream);
+    return orlg_state_copy(phy_state_parts(e), buffer, true, e->device, e->stream);
 }
 int orlg_phy_load_state(orlg_phy_env *e, const void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return state_copy(phy_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    return orlg_state_copy(phy_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
 }
 int orlg_phy_channel_state_capacity(orlg_phy_env *e) { return e ? e->p.cs_len : ORLG_ERR_INVALID; }
 int orlg_phy_get_channel_state(orlg_phy_env *e, int32_t env_index, uint32_t *entries, uint8_t *lengths) {

@@ -90,6 +90,7 @@ struct OrlgPhyParams {
     const int32_t *act_path;      // external actions: [B] path (-2 = blocked)
     const int16_t *act_channels;  // [B][ORLG_PHY_MAX_CH], -1 terminated; channel | used << 9 (used 0 = the full capacity)
     void *outs[ORLG_PHY_NUM_OUTS];
+    int32_t *err_flag;            // the handle's sticky error word (mapped host memory): a queue / list overflow happened
     // per-wave LDS layout
     int32_t l_occ, l_nbt, l_nbi, l_mt, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
 };
@@ -510,7 +511,7 @@ DEV double wave_min_key(uint32_t key, bool has) {
 template <int W>
 DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
                              uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
-                             int &next_seq, double current_time, int req_src, int req_dst, int lane) {
+                             int &next_seq, double current_time, int req_src, int req_dst, int lane SEC_PARAMS) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
@@ -572,6 +573,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     }
     if (n_el > p.cand_cap) { overflow = true; n_el = p.cand_cap; }
     int gmoves = 0;
+    SEC(8);   // defragmentation: grooming walk
     {
         long long cursor = -1;
         bool stop = p.number_moves == 0;  // the reference returns at its first check
@@ -652,6 +654,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     }
     int cmoves = 0, cycles = 0;
     // ------------------------------------------------------------------ 2. physical pass
+    SEC(12);  // defragmentation: candidate scan
     if (gmoves <= p.number_moves) {
         int nc = 0;
         for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
@@ -697,6 +700,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         }
         if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
         wave_sync();
+        SEC(14);  // defragmentation: candidate rounds
         for (int round = 0; round < nc; ++round) {  // every round retires one candidate
             // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
             double bd = -1.0, ba = 0.0;
@@ -1338,7 +1342,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             wave_sync();
             const long long processed = ws->c[0];
             if (processed % p.defrag_period == 0)
-                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane);
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane SEC_ARGS);
         }
 
         if (p.mode == ORLG_MODE_STEP) {
@@ -1381,6 +1385,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             go->n_running = n_running;
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
+            if (ws->q_overflow) *kp->err_flag = 1;   // reported by the next entry point that waits for the stream
             go->next_seq = next_seq; go->counted_moves = ws->counted_moves; go->counted_moves_groom = ws->counted_moves_groom;
             go->counted_defrag_cycles = ws->counted_defrag_cycles;
         }

@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .batched import COUNTER_NAMES, REQUEST_DTYPE, _ptr
+from .batched import COUNTER_NAMES, REQUEST_DTYPE, _check_buffer, _ptr
 from .topology import FrozenTopology, selection_tables
 
 PHY_DEFAULT_BIT_RATES = (100, 200, 300, 400, 500, 600)  # phy_rmsa_env.py:38
@@ -150,25 +150,43 @@ class BatchedPhyRMSAEnv:
     def reset(self, only_episode_counters: bool = True):
         _lib.check(self.L.orlg_phy_reset(self.h, 1 if only_episode_counters else 0))
 
+    def last_kernel(self) -> str:
+        """Name, template arguments and launch shape of the kernel behind the last ``run`` / ``reset``."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.L.orlg_phy_last_kernel(self.h, buf, 128))
+        return buf.value.decode()
+
     def run(self, policy: str, n_steps: int = 1, *, act_path=None, act_channels=None, auto_reset: bool = False,
-            outputs: Sequence[str] = ()):
+            outputs: Sequence[str] = (), out=None):
         """``n_steps`` x (policy -> PhyRMSAEnv.step).  ``policy='external'``: ``act_path`` [B] int32 (-2 = blocked,
         0..k-1 physical, 20 + k-path virtual layer) and ``act_channels`` [B, 14] int16 (-1 padded; entry = channel |
-        used << 9, see :func:`encode_channels`).  Returns the requested per-step arrays [n_steps, B(, ...)]."""
+        used << 9, see :func:`encode_channels`).  Returns the requested per-step arrays [n_steps, B(, ...)]; ``out`` may
+        supply preallocated numpy arrays or torch tensors by name (device tensors are written without staging)."""
         B = self.batch_size
         io = _lib.PhyStepIO()
         res = {}
-        for name in outputs:
+        names = list(outputs) + [k for k in (out or {}) if k not in outputs]
+        for name in names:
+            if name not in _lib.PHY_STEP_IO_DTYPES:
+                raise KeyError(f"unknown step output {name!r}")
             shape = {"request": (n_steps, B, 4), "channels": (n_steps, B, _lib.PHY_MAX_CHANNELS),
                      "channels_used": (n_steps, B, _lib.PHY_MAX_CHANNELS),
                      "defrag_counters": (n_steps, B, 3)}.get(name, (n_steps, B))
-            res[name] = np.zeros(shape, dtype=_lib.PHY_STEP_IO_DTYPES[name])
+            if out is not None and name in out:
+                res[name] = _check_buffer(f"out[{name!r}]", out[name], shape, _lib.PHY_STEP_IO_DTYPES[name])
+            else:
+                res[name] = np.zeros(shape, dtype=_lib.PHY_STEP_IO_DTYPES[name])
             setattr(io, name, _ptr(res[name]))
         ap = ac = None
-        if act_path is not None:
-            act_path = np.ascontiguousarray(act_path, np.int32)
-            act_channels = np.ascontiguousarray(act_channels, np.int16)
-            assert act_channels.shape == (B, _lib.PHY_MAX_CHANNELS)
+        if policy == "external":
+            if act_path is None or act_channels is None:
+                raise ValueError("policy 'external' needs act_path and act_channels")
+            if not hasattr(act_path, "data_ptr"):
+                act_path = np.ascontiguousarray(act_path, np.int32)
+            if not hasattr(act_channels, "data_ptr"):
+                act_channels = np.ascontiguousarray(act_channels, np.int16)
+            _check_buffer("act_path", act_path, (B,), np.int32)
+            _check_buffer("act_channels", act_channels, (B, _lib.PHY_MAX_CHANNELS), np.int16)
             ap, ac = _ptr(act_path), _ptr(act_channels)
         _lib.check(self.L.orlg_phy_step(self.h, _lib.PHY_POLICIES[policy], int(n_steps), ap, ac,
                                         1 if auto_reset else 0, C.byref(io)))

@@ -33,6 +33,12 @@ DEFAULT_BIT_RATES = [200, 250, 300, 350, 400, 450, 500, 550, 600, 650, 700, 750,
                      1050, 1100, 1150, 1200]
 
 
+# SURVEY 8(d) config 4 / BASELINE configs[3]: the DeepRMSA node request probabilities of the reference's own test
+# (tests/test_deeprmsa.py:30-47) -- parameter values, NSFNET node order
+DEEPRMSA_NODE_PROBS = [0.01801802, 0.04004004, 0.05305305, 0.01901902, 0.04504505, 0.02402402, 0.06706707, 0.08908909,
+                       0.13813814, 0.12212212, 0.07607608, 0.12012012, 0.01901902, 0.16916917]
+
+
 def oracle_env_from_kwargs(topo, env_kwargs, seed=None, j=1, reward_mode=0, asan=False):
     """Build an oracle env from reference-style RMSAEnv kwargs (rmsa_env.py:29-53)."""
     import oracle as orc

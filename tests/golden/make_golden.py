@@ -21,7 +21,6 @@ Outputs
 import argparse
 import json
 import os
-import pickle
 import sys
 import types
 import zlib
@@ -86,18 +85,33 @@ def install_gym_stub():
         sys.path.insert(0, REF)
 
 
-def load_pickled_topology(fname):
-    with open(os.path.join(REF, "examples", "topologies", fname), "rb") as f:
-        return pickle.load(f)
+def load_pickled_topology(spec):
+    """The topology graph the reference's environments take (``topology.graph["ksp" | "modulations" | ...]``).
+
+    The shipped ``examples/topologies/*.h5`` files are pickles: they are NOT loaded (unpickling public files can run
+    arbitrary code).  The graph is rebuilt from the link-list text file next to them with the reference's own
+    generator, ``examples/create_topology.py::get_topology`` (imported, unmodified) and its modulation table --
+    the same call that produced the pickles (``tests/test_topology_io.py`` holds our own front-end to the same
+    frozen tables).  The historic name of this helper is kept for the call sites below."""
+    import contextlib
+    import io
+    txt, k = spec
+    ex = os.path.join(REF, "examples")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)
+    import create_topology as ct   # main-guarded script: importing it only defines get_topology + the modulation table
+    name = os.path.splitext(txt)[0].upper()   # the shipped pickles carry the upper-case name (e.g. "NSFNET_CHEN")
+    with contextlib.redirect_stdout(io.StringIO()):   # get_topology prints every path
+        return ct.get_topology(os.path.join(ex, "topologies", txt), name, ct.modulations, k)
 
 
 # --------------------------------------------------------------------------- topologies
-TOPOLOGIES = {
-    "nsfnet_chen_5-paths_6-modulations": "nsfnet_chen_5-paths_6-modulations.h5",
-    "us14_3-paths_6-modulations": "us14_3-paths_6-modulations.h5",
-    "jpn12_3-paths_6-modulations": "jpn12_3-paths_6-modulations.h5",
-    "jpn12_5-paths_6-modulations": "jpn12_5-paths_6-modulations.h5",
-    "spn_3-paths_6-modulations": "spn_3-paths_6-modulations.h5",
+TOPOLOGIES = {   # fixture name -> (link-list file, k shortest paths)
+    "nsfnet_chen_5-paths_6-modulations": ("nsfnet_chen.txt", 5),
+    "us14_3-paths_6-modulations": ("us14.txt", 3),
+    "jpn12_3-paths_6-modulations": ("jpn12.txt", 3),
+    "jpn12_5-paths_6-modulations": ("jpn12.txt", 5),
+    "spn_3-paths_6-modulations": ("spn.txt", 3),
 }
 
 
@@ -369,6 +383,9 @@ DEEPRMSA_CASES = [
     ("deeprmsa_nsfnet_s10_spff", "nsfnet_chen_5-paths_6-modulations", dict(), "deeprmsa_sp_ff", 600, True),
     ("deeprmsa_nsfnet_s10_sapff_320", "nsfnet_chen_5-paths_6-modulations",
      dict(num_spectrum_resources=320, node_request_probabilities=None, mean_service_inter_arrival_time=1.0 / 24.0),
+     "deeprmsa_sap_ff", 1000, True),
+    # SURVEY 8(d) config 4 / BASELINE configs[3] exactly: S = 320, inter-arrival 1/12, the DeepRMSA node probabilities
+    ("deeprmsa_nsfnet_s10_sapff_320_config4", "nsfnet_chen_5-paths_6-modulations", dict(num_spectrum_resources=320),
      "deeprmsa_sap_ff", 1000, True),
     ("deeprmsa_nsfnet_s4_random_j3", "nsfnet_chen_5-paths_6-modulations",
      dict(seed=4, j=3, num_spectrum_resources=160, mean_service_inter_arrival_time=1.0 / 10.0), "random", 1000, True),

@@ -74,12 +74,14 @@ def test_deeprmsa_golden(case, device_log_in_oracle):
 
 
 def test_deeprmsa_observation_batch_32768(device_log_in_oracle):
-    """BASELINE config 4 size (B = 32 768, NSFNET S=320 j=1): observation build for the whole batch; spot
-    checks against the oracle and structural properties for every env."""
+    """SURVEY 8(d) config 4 / BASELINE configs[3] as written (B = 32 768, NSFNET S=320 j=1, holding 7.5, inter-arrival
+    1/12, the DeepRMSA node request probabilities of the reference's tests/test_deeprmsa.py:30-47): observation build for the
+    whole batch; spot checks against the oracle and structural properties for every env."""
     topo = load_topology("nsfnet_chen_5-paths_6-modulations")
+    from conftest import DEEPRMSA_NODE_PROBS
     from optical_rl_gym_amd import BatchedDeepRMSAEnv
-    kw = dict(j=1, mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 24.0,
-              num_spectrum_resources=320, episode_length=50, seed=100)
+    kw = dict(j=1, mean_service_holding_time=7.5, mean_service_inter_arrival_time=1.0 / 12.0,
+              node_request_probabilities=DEEPRMSA_NODE_PROBS, num_spectrum_resources=320, episode_length=50, seed=100)
     B = 32768
     env = BatchedDeepRMSAEnv(topo, B, step_kernel=STEP_KERNEL, **kw)
     env.run("deeprmsa_sap_ff", 300, auto_reset=True)
@@ -91,7 +93,7 @@ def test_deeprmsa_observation_batch_32768(device_log_in_oracle):
     assert np.array_equal(obs[:, 1:15].argmax(axis=1), np.minimum(req["src"], req["dst"]))
     assert np.array_equal(obs[:, 15:29].argmax(axis=1), np.maximum(req["src"], req["dst"]))
     okw, j = deeprmsa_to_rmsa_kwargs(kw)
-    for i in (0, 5, 4097, 32767):
+    for i in (0, 5, 4097, 16384, 20000, 32767):
         o = oracle_env_from_kwargs(topo, okw, seed=100 + i, j=j, reward_mode=1)
         o.run("deeprmsa_sap_ff", 300, reset_on_done=True, fields=[])
         assert np.array_equal(obs[i], o.observation()), i

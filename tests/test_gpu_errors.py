@@ -21,6 +21,45 @@ def test_rmsa_queue_overflow_is_reported(nsfnet):
     env.close()
 
 
+@pytest.mark.parametrize("kernel", ["wave", "group"])
+def test_overflow_is_returned_by_step_and_synchronize(nsfnet, kernel):
+    """A launch that loses a release makes the next call that waits for the stream fail: orlg_step with host outputs,
+    orlg_synchronize -- not only orlg_reduce_counters; read-back still works and a full reset clears the condition."""
+    from optical_rl_gym_amd import OrlgError
+    kw = dict(num_spectrum_resources=320, load=150, mean_service_holding_time=25, episode_length=1000, seed=1)
+    env = make_batched(nsfnet, kw, 16, queue_capacity=64, step_kernel=kernel)
+    with pytest.raises(OrlgError) as ei:
+        env.run("sap_ff", 3000, outputs=("accepted",))
+    assert ei.value.code == -4
+    env.run("sap_ff", 10)            # asynchronous launch: nothing to report yet
+    with pytest.raises(OrlgError) as ei:
+        env.synchronize()
+    assert ei.value.code == -4
+    assert env.num_running().max() >= 64      # state read-back is not blocked
+    env.reset(only_episode_counters=False)
+    env.run("sap_ff", 20, outputs=("accepted",))
+    env.synchronize()
+    env.close()
+
+
+def test_wrong_action_arrays_are_refused(nsfnet):
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=1)
+    env = make_batched(nsfnet, kw, 8)
+    with pytest.raises(ValueError):
+        env.run("external", 1, actions=np.zeros(8, np.int32))
+    with pytest.raises(ValueError):
+        env.run("external", 1)
+    with pytest.raises(TypeError):
+        env.run("deeprmsa_external", 1, actions=np.zeros(8, np.float64))
+    with pytest.raises(ValueError):
+        env.run("sap_ff", 4, out={"accepted": np.zeros((3, 8), np.uint8)})
+    with pytest.raises(TypeError):
+        env.run("sap_ff", 4, out={"accepted": np.zeros((4, 8), np.int32)})
+    r = env.run("external", 1, actions=np.zeros((8, 2), np.int64), outputs=("accepted",))   # integer arrays are converted
+    assert r["accepted"].shape == (1, 8)
+    env.close()
+
+
 def test_group_kernel_overflow_and_lds_limit(nsfnet):
     """The four-environments-per-wave kernel reports a full release queue like the other one, and a shape whose four
     environments do not fit the LDS is refused when that kernel is demanded (AUTO falls back to the wave-per-environment kernel)."""

@@ -1,0 +1,85 @@
+"""Full-size batches of BASELINE.json on the device, held to the oracle on sampled environments:
+the north-star batch (65 536 environments, four-environments-per-wave kernel picked by AUTO) and the topology groups of
+configs[4] (NSFNET / JPN12 / US14) at 8 192 environments each."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_topology, oracle_env_from_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def device_log_in_oracle():
+    import oracle as orc
+    from optical_rl_gym_amd import _lib
+    orc.set_log_fn(C.cast(_lib.load().orlg_host_log, C.c_void_p).value)
+    yield
+    orc.set_log_fn(None)
+
+
+def _check_samples(env, topo, kw, policy, warm, n, tr, samples):
+    occ_w = env.occupancy_words()
+    now, cnt = env.current_time(), env.counters()
+    ls = env.link_stats()
+    S = kw["num_spectrum_resources"]
+    for i in samples:
+        o = oracle_env_from_kwargs(topo, kw, seed=kw["seed"] + i)
+        o.run(policy, warm, fields=[])
+        ot = o.run(policy, n)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]) and np.array_equal(tr["act_slot"][:, i], ot["act_slot"]), i
+        assert np.array_equal(tr["accepted"][:, i], ot["accepted"]), i
+        bits = np.unpackbits(occ_w[i].view(np.uint8), axis=-1, bitorder="little")[:, :S]
+        assert np.array_equal(bits, o.available_slots()), i
+        assert now[i] == o.current_time(), i
+        oc = o.counters()
+        for name in oc:
+            assert cnt[name][i] == oc[name], (name, i)
+        ols = o.link_stats()
+        for name in ols:
+            assert np.array_equal(ls[name][i], ols[name]), (name, i)
+        o.close()
+
+
+def test_north_star_batch_65536(device_log_in_oracle):
+    """B = 65 536 on NSFNET-320 (the batch BASELINE.json's north_star quotes its target on, bench.py's headline): AUTO must
+    pick the four-environments-per-wave kernel; a long launch (ticket queue over 16 384 quads), short launches (static
+    striding) and a long launch with outputs; 12 sampled environments -- first / last of the batch, of a quad, of the
+    resident set -- bit-exact against the oracle on decisions, occupancy, clock, counters and link statistics."""
+    from optical_rl_gym_amd import BatchedRMSAEnv
+    topo = load_topology("nsfnet_chen_5-paths_6-modulations")
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=10)
+    B = 65536
+    env = BatchedRMSAEnv(topo, B, **kw)
+    env.run("sap_ff", 150)
+    assert env.last_kernel().startswith("orlg_rmsa_group_kernel<5,2>"), env.last_kernel()
+    for _ in range(2):
+        env.run("sap_ff", 3)
+    tr = env.run("sap_ff", 120, outputs=("act_path", "act_slot", "accepted"))
+    cnt = env.counters()
+    assert np.all(cnt["services_processed"] == 277)
+    assert np.array_equal(cnt["services_accepted"] >= tr["accepted"].sum(axis=0), np.ones(B, bool))
+    samples = (0, 1, 2, 3, 4, 11263, 11264, 16383, 32768, 50001, 65532, 65535)
+    _check_samples(env, topo, kw, "sap_ff", 156, 120, tr, samples)
+    red, _ = env.reduce_counters()
+    assert red["num_envs"] == B and red["services_processed"] == 277 * B
+    assert red["services_accepted"] == int(cnt["services_accepted"].sum())
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["nsfnet_chen_5-paths_6-modulations", "jpn12_5-paths_6-modulations", "us14_3-paths_6-modulations"])
+def test_mixed_topology_groups_8192(name, device_log_in_oracle):
+    """The three topology groups of BASELINE configs[4] (JPN12 stands in for "JPN48": SURVEY 0.7), 8 192 environments each on
+    the four-environments-per-wave kernel, sampled environments against the oracle."""
+    from optical_rl_gym_amd import BatchedRMSAEnv
+    topo = load_topology(name)
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=10)
+    B = 8192
+    env = BatchedRMSAEnv(topo, B, step_kernel="group", **kw)
+    env.run("sap_ff", 200)
+    tr = env.run("sap_ff", 150, outputs=("act_path", "act_slot", "accepted"))
+    assert env.last_kernel().startswith("orlg_rmsa_group_kernel"), env.last_kernel()
+    _check_samples(env, topo, kw, "sap_ff", 200, 150, tr, (0, 3, 4, 4095, 4096, 8190, 8191))
+    env.close()

@@ -173,14 +173,27 @@ def test_phy_external_virtual_layer_actions(device_log_in_oracle):
     env.close()
 
 
-def test_phy_batch_4096_properties():
-    """BASELINE config 3 size: B = 4096 PhyRMSA envs on US14."""
+def test_phy_batch_4096_properties(device_log_in_oracle):
+    """BASELINE config 3 size: B = 4096 PhyRMSA envs on US14 (load 1400, bmfa): size-independent properties for every env,
+    sampled envs bit-exact against the oracle incl. the per-step cut / RSS metrics."""
     z, meta = load_golden("phy_us14_s10_bmfa")
     topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
     kw = dict(meta["env_kwargs"], seed=100)
     env = make_env(topo, tables, kw, 4096)
-    tr = env.run("bmfa", 300, outputs=("accepted", "n_channels"), auto_reset=True)
+    tr = env.run("bmfa", 300, outputs=("accepted", "n_channels", "act_path", "channels", "number_cuts_total", "rss_total_metric"),
+                 auto_reset=True)
     cnt = env.counters()
+    av_all = env.available_channels()
+    for i in (0, 1, 63, 64, 2047, 4095):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=100 + i)
+        ot = o.run("bmfa", 300, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        assert np.array_equal(tr["rss_total_metric"][:, i], ot["rss_total_metric"]), i
+        assert np.array_equal(av_all[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        o.close()
     assert np.all(cnt["services_processed"] == 301)
     assert np.array_equal(cnt["services_accepted"], tr["accepted"].sum(axis=0))
     av = env.available_channels()

@@ -120,3 +120,24 @@ def test_registry_ids_resolve():
     with pytest.raises(KeyError):
         pkg.env_class("RWA-v0")   # out of scope
     assert pkg.register_with_gym() is None or hasattr(pkg.register_with_gym(), "make")
+
+
+def test_caller_buffers_are_validated():
+    """Arrays the C ABI reads or writes through raw pointers are checked for shape, dtype and layout first (a [B] array
+    for a [B, 2] action would be overrun, an int64 tensor reinterpreted)."""
+    from optical_rl_gym_amd.batched import _check_buffer
+    ok = np.zeros((3, 8), np.float64)
+    assert _check_buffer("out['reward']", ok, (3, 8), "float64") is ok
+    with pytest.raises(ValueError):
+        _check_buffer("actions", np.zeros(8, np.int32), (8, 2), np.int32)
+    with pytest.raises(TypeError):
+        _check_buffer("actions", np.zeros((8, 2), np.int64), (8, 2), np.int32)
+    with pytest.raises(ValueError):
+        _check_buffer("out['done']", np.zeros((8, 6), np.uint8)[:, ::2], (8, 3), np.uint8)
+    torch = pytest.importorskip("torch")
+    t = torch.zeros((8, 2), dtype=torch.int32)
+    assert _check_buffer("actions", t, (8, 2), np.int32) is t
+    with pytest.raises(TypeError):
+        _check_buffer("actions", torch.zeros((8, 2), dtype=torch.int64), (8, 2), np.int32)
+    with pytest.raises(ValueError):
+        _check_buffer("actions", torch.zeros((2, 8), dtype=torch.int32).t(), (8, 2), np.int32)

@@ -19,9 +19,9 @@ def main():
     ap.add_argument("--phy", default=None, help="profile the PhyRMSA kernel with this policy (bmfa, sapff, ...) instead")
     ap.add_argument("--defrag", action="store_true")
     args = ap.parse_args()
-    src = os.path.join(PKG, "csrc", "orlg_api.hip")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                    "-DORLG_SECTIONS", "-I", os.path.join(PKG, "csrc"), src, "-o", LIB], check=True)
+    sys.path.insert(0, PKG)
+    import build as orlg_build   # single-translation-unit build (csrc/orlg_unity.hip, W = 5: NSFNET-320 / US14-268)
+    orlg_build.build_unity(LIB, ["-DORLG_SECTIONS"], w=5, verbose=False)
     os.environ["ORLG_LIB_PATH"] = LIB
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -35,8 +35,8 @@ def main():
                                 gsnr=gsnr, load=1400, mean_service_holding_time=25, episode_length=200, seed=10,
                                 defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None)
         names = ["idle/ticket", "state load", "policy: virtual layer", "policy: row metrics", "policy: channel selection", "provision",
-                 "outputs", "next arrival + RNG", "", "release: buffer / rebuild", "release apply (+ next scan)", "defragmentation", "",
-                 "state store", "", ""]
+                 "outputs", "next arrival + RNG", "defrag: grooming walk", "release: buffer / rebuild", "release apply (+ next scan)",
+                 "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", ""]
         env.run(args.phy, 3000, auto_reset=True)
         L = _lib.load()
         out = (C.c_ulonglong * 16)()
@@ -45,7 +45,7 @@ def main():
         env.synchronize()
         L.orlg_debug_sections(out, 1)
         tot = sum(out)
-        res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(14) if names[i]}
+        res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(15) if names[i]}
         res["cycles_per_env_step"] = tot / (args.batch * args.steps)
         print(json.dumps({"kernel": "phy", "policy": args.phy, "defrag": args.defrag, "percent_of_wave_cycles": res}))
         return

@@ -27,9 +27,9 @@ def main():
     skip = set(sys.argv[1:])
     assume = " ".join("__builtin_assume(p.%s==%d);" % (f, v) for f, v in vals.items() if f not in skip)
     lib = os.path.join(PKG, "liborlg_shape.so")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                    "-DORLG_SHAPE_ASSUME=" + assume, "-I", os.path.join(PKG, "csrc"), os.path.join(PKG, "csrc", "orlg_api.hip"),
-                    "-o", lib], check=True)
+    sys.path.insert(0, PKG)
+    import build as orlg_build
+    orlg_build.build_unity(lib, ["-DORLG_SHAPE_ASSUME=" + assume], w=5, verbose=False)
     for tag, envv in (("generic", {}), ("shape", {"ORLG_LIB_PATH": lib})):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-north-star"],
                            env={**os.environ, **envv}, capture_output=True, text=True)
