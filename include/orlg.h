@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORLG_ABI_VERSION 1
+#define ORLG_ABI_VERSION 2
 
 enum {
     ORLG_OK = 0,

@@ -40,7 +40,7 @@ struct __attribute__((aligned(16))) OrlgEnvScalars {
     int32_t q_overflow;                                    // release queue overflowed (error)
     int32_t ring_pos, ring_cnt;                            // pre-generated arrivals: next entry, entries left
     int32_t sum_span, sum_gaps;                            // sums over the per-link (span, gaps) cache (_get_network_compactness)
-    int32_t pad;
+    int32_t q_head;                                        // release queue: slot of the earliest entry (time-sorted ring, see OrlgParams::qtime)
 };
 static_assert(sizeof(OrlgEnvScalars) == 192, "OrlgEnvScalars layout");
 
@@ -73,6 +73,9 @@ struct OrlgParams {
     double arrival_lambda, holding_lambda;
     // per-env state in HBM
     uint64_t *occ;            // [B][NW]   free-slot bitmap, word (link*W + w)
+    // release queue (the reference's heapq of (release time, service), optical_network_env.py:178-189): a time-sorted ring.  The
+    // n_running entries sit at slots (q_head + rank) % Q in ascending release time; every other slot holds (+inf, 0).  A
+    // release pops the head, an insert moves the later entries up by one slot.
     double *qtime;            // [B][Q]    release time, +inf = empty slot
     uint32_t *qdesc;          // [B][Q]    path gid | start << 14 | bit-rate index << 24
     uint32_t *mt;             // [B][624]

@@ -280,18 +280,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     wave_sync();
     double comp_cur = 1.0;
     if (NET) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
-    // release queue: every lane keeps the earliest entry of its own slots (gl, gl + 16, ...) in registers -- an insert updates
-    // the receiving lane's, a release makes the lanes look at their slots again -- and the row the time of its earliest entry
-    double lm_t = INF;
-    int lm_q = 0x7fffffff, q_top = 0, q_low = 0;  // slots at or beyond q_top are empty, slots below q_low occupied
-    for (int j = gl; j < Q; j += ORLG_GL) {
-        const double tq = qtime[j];
-        if (tq < lm_t) { lm_t = tq; lm_q = j; }
-        if (tq < INF) q_top = j + 1;
-    }
-    q_top = -row_min_i32(-q_top);
-    double next_rel = lm_t;
-    { int dummy = lm_q; row_min_time_slot(next_rel, dummy); }
+    // release queue: a time-sorted ring in LDS (OrlgParams::qtime) -- q_n entries from slot q_head on; the row keeps the time of
+    // its head in a register, so that a step without a due release touches no queue memory
+    int q_head = gs->q_head, q_n = n_running < Q ? n_running : Q;   // (n_running also counts services an overflow lost)
+    double next_rel = qtime[q_head];   // +inf when the queue is empty
     const int cidx = gl & 7;
     int req_base = tb.pair_base[req_src * N + req_dst];  // first path record of the pending request's node pair
 
@@ -412,37 +404,41 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                                             sum_gaps, comp_cur, sum_sh, (double)sum_bitrate_running, g_thr, g_comp, g_lu);
         SEC(5);  // queue insert
         {
-            // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
+            // ---- _add_release (optical_network_env.py:178-189): the entries that are released later move up one slot (from the
+            // top chunk of 16 down: a chunk's reads precede its writes), the new one takes the slot that opens -- each row its own
             const double rel = req_arrival + req_holding;
-            // every slot below q_low is occupied (an insert raises it past the slot it took, a release lowers it to the slot it
-            // freed), so the scan starts at q_low's chunk -- each row at its own
-            bool placed = !accepted;
-            int q0 = q_low & ~(ORLG_GL - 1);
-            while (ballot(!placed) != 0ull) {
-                const bool scan = !placed && q0 < Q;
+            bool ins = accepted;
+            if (ins && q_n >= Q) { q_overflow = 1; ins = false; }
+            bool found = !ins;
+            int r = 0, j0 = (q_n - 1) & ~(ORLG_GL - 1);   // q_n == 0: j0 < 0, nothing to move
+            while (ballot(!found && j0 >= 0) != 0ull) {
+                const bool scan = !found && j0 >= 0;
+                const int j = j0 + gl;
+                const bool valid = scan && j < q_n;
+                int pos = q_head + j;
+                pos -= pos >= Q ? Q : 0;
                 double tq = 0.0;
-                if (scan) tq = qtime[q0 + gl];
-                const uint32_t em = row_ballot(scan && __double_as_longlong(tq) == (long long)ORLG_INF_BITS, lane);
-                if (!placed) {
-                    if (q0 >= Q) {
-                        q_overflow = 1;
-                        placed = true;
-                    } else if (em) {
-                        const int l = __builtin_ctz(em);
-                        if (gl == l) {
-                            qtime[q0 + l] = rel;
-                            qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
-                            if (rel < lm_t || (rel == lm_t && q0 + l < lm_q)) { lm_t = rel; lm_q = q0 + l; }
-                        }
-                        q_top = q0 + l + 1 > q_top ? q0 + l + 1 : q_top;
-                        q_low = q0 + l + 1;
-                        placed = true;
-                    } else {
-                        q0 += ORLG_GL;
-                    }
+                uint32_t dq = 0u;
+                if (valid) { tq = qtime[pos]; dq = qdesc[pos]; }
+                const bool later = valid && tq > rel;
+                const int pos1 = pos + 1 == Q ? 0 : pos + 1;
+                if (later) { qtime[pos1] = tq; qdesc[pos1] = dq; }
+                const uint32_t le = row_ballot(valid && !later, lane);   // sorted: a prefix of the chunk
+                if (scan) {
+                    if (le) { r = j0 + __builtin_popcount(le); found = true; }
+                    else j0 -= ORLG_GL;
                 }
             }
-            if (accepted) next_rel = rel < next_rel ? rel : next_rel;
+            if (ins) {
+                int pr = q_head + r;
+                pr -= pr >= Q ? Q : 0;
+                if (gl == 0) {
+                    qtime[pr] = rel;
+                    qdesc[pr] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
+                }
+                q_n += 1;
+                next_rel = rel < next_rel ? rel : next_rel;
+            }
             wave_sync();
         }
 
@@ -531,40 +527,31 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 if (gl == 0) { atomicAdd(ghist + req_br, 1); atomicAdd(ghist + 2 * NBR + req_br, 1); }
             }
 
-            // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
+            // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695): the ring's head
             bool released = false;
             for (;;) {
                 SEC(9);  // release scan
-                const bool due = act && next_rel <= current_time;
-                if (ballot(due) == 0ull) break;
-                double bt = lm_t;
-                int bq = lm_q;
-                row_min_time_slot(bt, bq);
-                const bool rel_now = due && bt <= current_time;
-                if (due && !rel_now) next_rel = bt;  // the queue's earliest entry lies ahead: no scan until then
+                const bool rel_now = act && next_rel <= current_time;
                 if (ballot(rel_now) == 0ull) break;
                 SEC(10);  // release apply
                 // ---- _release_path (rmsa_env.py:515-535)
                 uint32_t d = 0;
-                if (rel_now) d = qdesc[bq];
+                if (rel_now) d = qdesc[q_head];
                 const int gid2 = (int)(d & 0x3fff), s0 = (int)((d >> 14) & 0x3ff), bri2 = (int)(d >> 24);
                 const OrlgPathRec *rec2 = tb.recs + gid2;
                 const int hops2 = rec2->hops;
                 const int n2 = tb.nslots[bri2 * ORLG_NSLOT_STRIDE + rec2->se];
                 if (rel_now) {
-                    if (gl == (bq & 15)) qtime[bq] = INF;
-                    q_low = bq < q_low ? bq : q_low;
+                    if (gl == 0) { qtime[q_head] = INF; qdesc[q_head] = 0u; }
+                    q_head = q_head + 1 == Q ? 0 : q_head + 1;
+                    q_n -= 1;
                     n_running -= 1;
                     sum_bitrate_running -= tb.bit_rates[bri2];
                     sum_sh -= n2 * hops2;
                     released = true;
                 }
-                group_apply_window<W>(lane, occ, rec2->link, rel_now ? hops2 : 0, s0, n2, true);
-                lm_t = INF; lm_q = 0x7fffffff;
-                for (int j = gl; j < q_top; j += ORLG_GL) {
-                    const double tq = qtime[j];
-                    if (tq < lm_t) { lm_t = tq; lm_q = j; }
-                }
+                group_apply_window<W>(lane, occ, rec2->link, rel_now ? hops2 : 0, s0, n2, true);   // (ends with a wave_sync)
+                if (rel_now) next_rel = qtime[q_head];   // the next entry, +inf when none is left
                 SEC(11);  // statistics at release
                 if (NET)
                     group_link_stats<W, FULL, false>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
@@ -618,7 +605,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = q_overflow;
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
-            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
+            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->q_head = q_head;
             if (q_overflow) *p.err_flag = 1;   // reported by the next entry point that waits for the stream
         }
     }

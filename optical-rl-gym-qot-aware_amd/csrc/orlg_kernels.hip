@@ -538,24 +538,25 @@ DEV u64 path_word_rec(const u64 *occ, const OrlgPathRec *recs, int gid, int w, b
 
 // Bits b of word w such that slots [64 w + b, 64 w + b + n) are all free, for a bitmap whose W words sit on W consecutive lanes
 // of a row (w = the lane's word; `x` = 0 on lanes that hold nothing).  r_m = AND of x >> 0 .. x >> (m - 1) is doubled:
-// r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 32 so that a shift needs the next word only.  n may differ between the rows (and
-// between the paths inside a row): the loop runs to the longest, finished lanes stand still.
+// r_{m+k} = r_m & (r_m >> k) for k <= m; k <= 31, so that a shift is two 32-bit funnel shifts (v_alignbit_b32) fed by the next
+// word's low half (one DPP read).  n may differ between the rows (and between the paths inside a row): the loop runs to the
+// longest, a finished lane shifts by k = 0, which leaves it as it is -- no predication.
 template <int W>
 DEV u64 run_starts(u64 x, int n, int w) {
-    u64 r = x;
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t keep = w == W - 1 ? 0u : ~0u;  // nothing beyond the last word
     int have = 1;
     for (;;) {
         int k = n - have;
         k = k < have ? k : have;
-        k = k < 32 ? k : 32;
+        k = k < 31 ? k : 31;
         if (ballot(k > 0) == 0ull) break;
-        u64 nxt = lane_next_u64(r);
-        if (w == W - 1) nxt = 0ull;  // nothing beyond the last word
-        const int kk = k > 0 ? k : 1;
-        const u64 sh = (r >> kk) | (nxt << (64 - kk));
-        if (k > 0) { r &= sh; have += k; }
+        const uint32_t nlo = (uint32_t)lane_next_i32((int)lo) & keep;
+        const uint32_t slo = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)k), shi = __builtin_amdgcn_alignbit(nlo, hi, (uint32_t)k);
+        lo &= slo; hi &= shi;
+        have += k;
     }
-    return r;
+    return ((u64)hi << 32) | lo;
 }
 
 template <int W, bool LINKF, bool GRAPH>
@@ -853,6 +854,8 @@ DEV void rmsa_body(const OrlgParams &p) {
     const int gs_sum_span = gs->sum_span, gs_sum_gaps = gs->sum_gaps;
     int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
+    // release queue: a time-sorted ring in LDS -- q_n entries from slot q_head on, ascending release time (OrlgParams::qtime)
+    int q_head = gs->q_head, q_n = gs->n_running < Q ? gs->n_running : Q;   // (n_running also counts services an overflow lost)
     int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
     if (lane == 0) {
@@ -1003,21 +1006,35 @@ DEV void rmsa_body(const OrlgParams &p) {
                     }
                     accepted = true;
                     SEC(5);  // queue insert
-                    // ---- _add_release (optical_network_env.py:178-189): first empty queue slot
-                    double rel = wv.wsc->req_arrival + wv.wsc->req_holding;
-                    bool placed = false;
-                    for (int q0 = 0; q0 < Q && !placed; q0 += 64) {
-                        u64 m = ballot(__double_as_longlong(wv.qtime[q0 + lane]) == (long long)ORLG_INF_BITS);
-                        if (m) {
-                            int l = ctz64(m);
-                            if (lane == l) {
-                                wv.qtime[q0 + l] = rel;
-                                wv.qdesc[q0 + l] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
-                            }
-                            placed = true;
+                    // ---- _add_release (optical_network_env.py:178-189): the entries that are released later move up one slot
+                    // (from the top chunk down: a chunk's reads precede its writes), the new one takes the slot that opens
+                    const double rel = wv.wsc->req_arrival + wv.wsc->req_holding;
+                    if (q_n >= Q) {
+                        if (lane == 0) wv.wsc->q_overflow = 1;
+                    } else {
+                        int r = 0;
+                        for (int j0 = (q_n - 1) & ~63; j0 >= 0; j0 -= 64) {
+                            const int j = j0 + lane;
+                            const bool valid = j < q_n;
+                            int pos = q_head + j;
+                            pos -= pos >= Q ? Q : 0;
+                            double tq = 0.0;
+                            uint32_t dq = 0u;
+                            if (valid) { tq = wv.qtime[pos]; dq = wv.qdesc[pos]; }
+                            const bool later = valid && tq > rel;
+                            const int pos1 = pos + 1 == Q ? 0 : pos + 1;
+                            if (later) { wv.qtime[pos1] = tq; wv.qdesc[pos1] = dq; }
+                            const u64 le = ballot(valid && !later);   // sorted: a prefix of the chunk
+                            if (le) { r = j0 + popc64(le); break; }
                         }
+                        int pr = q_head + r;
+                        pr -= pr >= Q ? Q : 0;
+                        if (lane == 0) {
+                            wv.qtime[pr] = rel;
+                            wv.qdesc[pr] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
+                        }
+                        q_n += 1;
                     }
-                    if (!placed && lane == 0) wv.wsc->q_overflow = 1;
                     wave_sync();
                 }
             }
@@ -1115,35 +1132,28 @@ DEV void rmsa_body(const OrlgParams &p) {
                 wv.hist[2 * NBR + bri] += 1;
             }
 
-            // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695)
+            // ---- release every service with release time <= now, in time order (rmsa_env.py:689-695): the ring's head
             bool released = false;
             for (;;) {
                 SEC(9);  // release scan
-                double best_t = 0.0;
-                int best_q = -1;
-                for (int q0 = 0; q0 < Q; q0 += 64) {
-                    double tq = wv.qtime[q0 + lane];
-                    u64 m = ballot(tq <= current_time);
-                    while (m) {
-                        int l = ctz64(m);
-                        m &= m - 1;
-                        double tt = readlane_d(tq, l);
-                        if (best_q < 0 || tt < best_t) { best_t = tt; best_q = q0 + l; }
-                    }
-                }
-                if (best_q < 0) break;
+                if (q_n == 0) break;
+                const double t_head = wv.qtime[q_head];   // every lane reads the same slot
+                if (!(readlane_d(t_head, 0) <= current_time)) break;
                 SEC(10);  // release apply
                 // ---- _release_path (rmsa_env.py:515-535)
-                const uint32_t d = wv.qdesc[best_q];
+                const uint32_t d = (uint32_t)uni((int)wv.qdesc[q_head]);
                 const int gid = (int)(d & 0x3fff), s0 = (int)((d >> 14) & 0x3ff), bri2 = (int)(d >> 24);
                 const OrlgPathRec *rec = tb.recs + gid;
                 const int hops = rec->hops, se = rec->se;
                 const int n = tb.nslots[bri2 * ORLG_NSLOT_STRIDE + se];
                 if (lane == 0) {
-                    wv.qtime[best_q] = __longlong_as_double((long long)ORLG_INF_BITS);
+                    wv.qtime[q_head] = __longlong_as_double((long long)ORLG_INF_BITS);
+                    wv.qdesc[q_head] = 0u;
                     wv.wsc->n_running -= 1;
                     wv.wsc->sum_bitrate_running -= tb.bit_rates[bri2];
                 }
+                q_head = q_head + 1 == Q ? 0 : q_head + 1;
+                q_n -= 1;
                 apply_window<W>(wv, rec->link, hops, s0, n, true);
                 sum_sh -= n * hops;
                 SEC(11);  // statistics at release
@@ -1212,7 +1222,7 @@ DEV void rmsa_body(const OrlgParams &p) {
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
             go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
-            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->pad = 0;
+            go->sum_span = sum_span; go->sum_gaps = sum_gaps; go->q_head = q_head;
             if (ws->q_overflow) *kp->err_flag = 1;   // reported by the next entry point that waits for the stream
         }
         wave_sync();
