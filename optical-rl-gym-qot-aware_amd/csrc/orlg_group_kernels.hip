@@ -46,26 +46,27 @@ DEV void row_min_time_slot(double &t, int &q) {
 }
 
 // Reductions over the W consecutive lanes that hold one link's words (W is not a power of two in general: 16 / W links share a
-// row): lane i combines lanes i .. i + W - 1 of its row with DPP row_shl:k, so the link's FIRST lane ends with the link's
-// result (the other lanes hold partial results nobody reads).  A source past the row's end leaves the identity in place.
-template <int K>
-DEV int dpp_row_shl(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x100 + K, 0xf, 0xf, false); }
-#define ORLG_SEG_REDUCE(name, IDENT, OP)                                                   \
-    template <int W>                                                                       \
-    DEV int name(int v) {                                                                  \
-        int a = v, o;                                                                      \
-        if (W > 1) { o = dpp_row_shl<1>(IDENT, v); a = OP; }                               \
-        if (W > 2) { o = dpp_row_shl<2>(IDENT, v); a = OP; }                               \
-        if (W > 3) { o = dpp_row_shl<3>(IDENT, v); a = OP; }                               \
-        if (W > 4) { o = dpp_row_shl<4>(IDENT, v); a = OP; }                               \
-        if (W > 5) { o = dpp_row_shl<5>(IDENT, v); a = OP; }                               \
-        if (W > 6) { o = dpp_row_shl<6>(IDENT, v); a = OP; }                               \
-        if (W > 7) { o = dpp_row_shl<7>(IDENT, v); a = OP; }                               \
-        return a;                                                                          \
+// row): the link's FIRST lane ends with the link's result (the other lanes hold partial results nobody reads).  Sums and
+// unsigned maxima only: a source past the row's end reads as 0 (bound_ctrl), their identity, so that every step is ONE
+// instruction (v_add_u32_dpp / v_max_u32_dpp); a doubling tree: lanes i, i+1 -> i .. i+3 -> the rest.
+#define ORLG_SEG_REDUCE(name, OP)                                                                   \
+    template <int W>                                                                                \
+    DEV uint32_t name(uint32_t v) {                                                                 \
+        static_assert(W >= 1 && W <= 8 && W != 7, "words per link");                                \
+        if (W == 1) return v;                                                                       \
+        uint32_t o = (uint32_t)lane_ahead_i32<1>((int)v);                                           \
+        const uint32_t s = OP(v, o);                                   /* lanes i, i+1 */           \
+        if (W == 2) return s;                                                                       \
+        o = (uint32_t)lane_ahead_i32<2>((int)(W == 3 ? v : s));                                     \
+        const uint32_t t = OP(s, o);                                   /* lanes i .. i+2 / i+3 */   \
+        if (W <= 4) return t;                                                                       \
+        o = (uint32_t)lane_ahead_i32<4>((int)(W == 5 ? v : (W == 6 ? s : t)));                      \
+        return OP(t, o);                                               /* lanes i .. i+W-1 */       \
     }
-ORLG_SEG_REDUCE(seg_add, 0, a + o)
-ORLG_SEG_REDUCE(seg_min, 0x7fffffff, (o < a ? o : a))
-ORLG_SEG_REDUCE(seg_max, 0, (o > a ? o : a))
+#define ORLG_OP_ADD(a, b) ((a) + (b))
+#define ORLG_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+ORLG_SEG_REDUCE(seg_add, ORLG_OP_ADD)
+ORLG_SEG_REDUCE(seg_max, ORLG_OP_MAX)
 #undef ORLG_SEG_REDUCE
 
 // link statistics of up to ORLG_MAX_HOPS links per row: link_stats_update (orlg_kernels.hip) with 16 / W links per row and
@@ -84,7 +85,8 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         if (ballot(h0 < nlinks) == 0ull) break;
         const int h = h0 + sl;
         const bool on = sl < NS && h < nlinks;
-        int link = 0, packed = 0, lo = 0x7fff, hi = 0, ml = 0;
+        int link = 0;
+        uint32_t packed = 0u, ilo = 0u, hi = 0u, ml = 0u;   // ilo = 0x7fff - first used slot (0: none): the minimum taken as a maximum
         if (on) link = (int)links[h];
         // the link's words sit on consecutive lanes: the neighbours' words arrive by DPP instead of further LDS reads
         u64 x = 0ull;
@@ -106,31 +108,35 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         }
         const bool first_free = x & 1ull;                                                     // meaningful on w == 0
         // slot S - 1 sits in word (S - 1) >> 6 -- not always the last of the W words (S = 400 runs on the 8-word layout)
-        const int last_free_bit = w == ((S - 1) >> 6) ? (int)((x >> ((S - 1) & 63)) & 1ull) : 0;
-        const bool last_free = seg_max<W>(last_free_bit) != 0;  // on the link's first lane
+        const uint32_t last_free_bit = w == ((S - 1) >> 6) ? (uint32_t)((x >> ((S - 1) & 63)) & 1ull) : 0u;
+        // ... on the link's first lane: slot S - 1 sits in the link's last word or in the one before it (W = ceil(S / 64), 8 for 7)
+        uint32_t lf = last_free_bit;
+        if (W > 1) lf |= (uint32_t)lane_ahead_i32<(W > 1 ? W - 1 : 1)>((int)last_free_bit);
+        if (W > 2) lf |= (uint32_t)lane_ahead_i32<(W > 2 ? W - 2 : 1)>((int)last_free_bit);
+        const bool last_free = lf != 0u;
         if (on) {
             u64 u = ~x & valid_mask(S, w);
             u64 carry_f = w > 0 ? (prev >> 63) : 0ull;
             u64 carry_u = w > 0 ? ((~prev) >> 63) : 0ull;
             u64 fstarts = x & ~((x << 1) | carry_f);
             u64 ustarts = u & ~((u << 1) | carry_u);
-            packed = popc64(x) | (popc64(fstarts) << 10) | (popc64(ustarts) << 20);  // free slots, free runs, used runs
-            lo = u ? 64 * w + ctz64(u) : 0x7fff;
-            hi = u ? 64 * w + 64 - clz64(u) : 0;
+            packed = (uint32_t)(popc64(x) | (popc64(fstarts) << 10) | (popc64(ustarts) << 20));  // free slots, free runs, used runs
+            ilo = u ? (uint32_t)(0x7fff - (64 * w + ctz64(u))) : 0u;
+            hi = u ? (uint32_t)(64 * w + 64 - clz64(u)) : 0u;
             if (LINKF) {
                 u64 st = fstarts;
                 while (st) {
                     int b = ctz64(st);
                     st &= st - 1;
-                    int len = free_run_length((~x) >> b, 64 - b + e);
+                    const uint32_t len = (uint32_t)free_run_length((~x) >> b, 64 - b + e);
                     ml = len > ml ? len : ml;
                 }
             }
         }
         packed = seg_add<W>(packed);
-        const int lmin = seg_min<W>(lo), lmax = seg_max<W>(hi);
+        const int lmin = 0x7fff - (int)seg_max<W>(ilo), lmax = (int)seg_max<W>(hi);
         if (LINKF) ml = seg_max<W>(ml);
-        const int freec = packed & 0x3ff, F = (packed >> 10) & 0x3ff, U = packed >> 20;
+        const int freec = (int)(packed & 0x3ff), F = (int)((packed >> 10) & 0x3ff), U = (int)(packed >> 20);
         const bool link_lane = on && w == 0;  // one lane per link carries on
         int dspan = 0, dgaps = 0;
         if (link_lane) {
@@ -149,7 +155,7 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
             const double cur0 = tb.div_s[S - freec];  // (S - free) / S
             double cur1 = 0.0, cur2 = 0.0;
             if (freec > 0) {
-                int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
+                int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? (int)ml : 0;
                 cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
                 cur2 = U > 1 ? ORLG_FDIV((double)(lmax - lmin), (double)(S - freec)) * tb.inv_k[U] : 1.0;
             }
@@ -501,7 +507,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 uint4 *o_mt = reinterpret_cast<uint4 *>(p.mt + (size_t)env_s * ORLG_MT_N);
                 o_mt[lane] = m0; o_mt[lane + 64] = m1;
                 if (lane < 156 - 128) o_mt[lane + 128] = m2;
-                __threadfence();  // the ring entries written by other lanes are read back through the vector cache below
+                // the ring entries written by other lanes are read back by this wave below: the stores have to be complete (same
+                // CU: the vector cache is write-through and coherent for its own CU's stores, no L2 write-back / invalidate needed)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 wave_sync();
                 if ((lane & 48) == src_lane) { ring_cnt = got; ring_pos = 0; mt_idx = idx_s; dry = false; }
             }

@@ -856,6 +856,7 @@ DEV void rmsa_body(const OrlgParams &p) {
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
     // release queue: a time-sorted ring in LDS -- q_n entries from slot q_head on, ascending release time (OrlgParams::qtime)
     int q_head = gs->q_head, q_n = gs->n_running < Q ? gs->n_running : Q;   // (n_running also counts services an overflow lost)
+    double next_rel = readlane_d(wv.qtime[q_head], 0);   // release time at the ring's head, +inf when the queue is empty
     int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
     if (lane == 0) {
@@ -1034,6 +1035,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                             wv.qdesc[pr] = (uint32_t)gid | ((uint32_t)a_slot << 14) | ((uint32_t)req_br << 24);
                         }
                         q_n += 1;
+                        if (r == 0) next_rel = rel;
                     }
                     wave_sync();
                 }
@@ -1136,9 +1138,7 @@ DEV void rmsa_body(const OrlgParams &p) {
             bool released = false;
             for (;;) {
                 SEC(9);  // release scan
-                if (q_n == 0) break;
-                const double t_head = wv.qtime[q_head];   // every lane reads the same slot
-                if (!(readlane_d(t_head, 0) <= current_time)) break;
+                if (!(next_rel <= current_time)) break;   // (a step without a due release touches no queue memory)
                 SEC(10);  // release apply
                 // ---- _release_path (rmsa_env.py:515-535)
                 const uint32_t d = (uint32_t)uni((int)wv.qdesc[q_head]);
@@ -1154,7 +1154,8 @@ DEV void rmsa_body(const OrlgParams &p) {
                 }
                 q_head = q_head + 1 == Q ? 0 : q_head + 1;
                 q_n -= 1;
-                apply_window<W>(wv, rec->link, hops, s0, n, true);
+                apply_window<W>(wv, rec->link, hops, s0, n, true);   // (ends with a wave_sync)
+                next_rel = readlane_d(wv.qtime[q_head], 0);          // the next entry, +inf when none is left
                 sum_sh -= n * hops;
                 SEC(11);  // statistics at release
                 if (NET)

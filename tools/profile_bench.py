@@ -149,12 +149,17 @@ def main():
     entry = {"batch": B, "env_steps_per_launch_per_env": chunk, "per_env_step": per_env,
              "source": f"profiles/{args.tag}_{key}_summary.json"}
     if "SQ_ACTIVE_INST_VALU" in pmc and pmc.get("SQ_WAVE_CYCLES"):
-        k0 = next(iter(per_kernel.values()))
-        # waves resident per SIMD: wave-cycles / busy cycles of the SQs over 4 SIMDs x 256 CUs is too indirect; use the launch shape
-        wg, lds = int(k0["workgroup"] or 0), int(k0["lds"] or 0)
+        # waves resident per SIMD from the launch shape the library reports (bench.py "launch": "... block=704 lds=158336")
+        import re
+        rec = bench_line if "launch" in bench_line else next(iter(bench_line.get("sub_records", {}).values()), {})
+        m = re.search(r"block=(\d+) lds=(\d+)", rec.get("launch", ""))
+        wg, lds = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
         waves_wg = wg // 64 if wg else 0
         wg_per_cu = min(160 * 1024 // lds if lds else 32, 32 // max(1, waves_wg)) if waves_wg else 0
-        entry["waves_per_simd"] = waves_wg * wg_per_cu / 4.0
+        k0 = next(iter(per_kernel.values()))
+        vg = int(k0.get("vgpr") or 0) + int(k0.get("accum_vgpr") or 0)
+        reg_waves = min(8, 512 // (((vg + 7) // 8) * 8)) if vg else 8   # MI355X_MICROARCH.md: 512 registers per lane and SIMD
+        entry["waves_per_simd"] = min(waves_wg * wg_per_cu / 4.0, float(reg_waves))
         entry["valu_busy"] = pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_WAVE_CYCLES"] * entry["waves_per_simd"]
         entry["valu_cycles_per_inst"] = 4.0 * pmc["SQ_ACTIVE_INST_VALU"] / pmc["SQ_INSTS_VALU"]
         summary["valu"] = {k: entry[k] for k in ("waves_per_simd", "valu_busy", "valu_cycles_per_inst")}
