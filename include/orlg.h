@@ -241,6 +241,14 @@ typedef struct orlg_phy_config {
     /* calculate_r_cut(modified=True) (phy_rmsa_env.py:1140-1193): per path the links adjacent to its nodes that are
      * not on the path, weight 1 at the end nodes and 2 at interior nodes (CSR over path records) */
     const int32_t *adj_off, *adj_link, *adj_weight;
+    /* Optional, networks of at most 16 nodes: the same metric through per-node free degrees.  With D[v][channel] = number of
+     * links at node v that are free on the channel, sum_j weight_j * available[link_j] = c . D[:, channel] - (the path's own
+     * links, if free) - (chords, if free), c[v] = 1 / 2 / 0 for an end / interior / off-path node; the library keeps D next
+     * to the occupancy (it changes by exactly c when a channel is taken or returned on a path) and evaluates the metric with
+     * byte dot products.  path_node_weights: [num_paths][32] records -- bytes 0..15 c, 16..17 sum of the adjacency weights
+     * (int16), 18..19 c . (path links per node) (int16), 20 number of chords (<= 5), 21..25 chord links, 26..30 chord
+     * weights; node_degree: [16] links per node.  NULL = adjacency lists only (identical results). */
+    const uint8_t *path_node_weights, *node_degree;
 } orlg_phy_config;
 
 enum {

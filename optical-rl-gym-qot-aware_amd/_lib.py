@@ -60,7 +60,8 @@ class PhyConfig(C.Structure):
                 ("defrag_capacity", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
-                                          "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight")]
+                                          "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight",
+                                          "path_node_weights", "node_degree")]
 
 
 class PhyStepIO(C.Structure):

@@ -43,6 +43,8 @@ __global__ void orlg_phy_clear_kernel(OrlgPhyParams p, int W, int keep_rng) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
     for (size_t i = tid; i < (size_t)p.B * p.NW; i += nth) p.occ[i] = valid_mask(p.C, (int)(i % W));
     for (size_t i = tid; i < (size_t)p.B * p.N * p.N * p.K; i += nth) p.cs_n[i] = 0;
+    if (p.use_nv)   // every link free: the nodes' degrees
+        for (size_t i = tid; i < (size_t)p.B * p.cpad; i += nth) p.nv[i] = p.deg;
     for (size_t i = tid; i < (size_t)p.B; i += nth) {
         OrlgPhyScalars s;
         memset(&s, 0, sizeof(s));
@@ -386,6 +388,18 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         hipError_t er = hipMemset(p.ticket, 0, 16);
         if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(er)); }
     }
+    // node-degree vectors of the cut metric (include/orlg.h, orlg_phy_config::path_node_weights): D[env][channel] = 16 bytes,
+    // links free at every node; L2-resident, updated whenever a channel is taken or returned on a path
+    p.use_nv = (c->path_node_weights && c->node_degree && N <= 16) ? 1 : 0;
+    if (p.use_nv) {
+        TRY(alloc(reinterpret_cast<void **>(&p.nv), (size_t)batch * p.cpad * sizeof(uint4)));
+        uint4 *d_rec = nullptr;
+        TRY(alloc(reinterpret_cast<void **>(&d_rec), (size_t)t->num_paths * 32));
+        hipError_t er = hipMemcpy(d_rec, c->path_node_weights, (size_t)t->num_paths * 32, hipMemcpyHostToDevice);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "upload of the node weight records: %s", hipGetErrorString(er)); }
+        p.nvrec = d_rec;
+        memcpy(&p.deg, c->node_degree, 16);
+    }
     if (p.defrag_period > 0) {
         // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
         p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;
@@ -554,7 +568,8 @@ static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
     const OrlgPhyParams &p = e->p;
     const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
     return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
-            {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists}};
+            {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists},
+            {p.nv, p.use_nv ? B * p.cpad * sizeof(uint4) : (size_t)0}};
 }
 int64_t orlg_phy_state_size(orlg_phy_env *e) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");

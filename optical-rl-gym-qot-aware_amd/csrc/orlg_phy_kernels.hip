@@ -31,8 +31,8 @@ struct __attribute__((aligned(16))) OrlgPhySvc {  // one running service (HBM)
 };
 // one entry of the per-env defragmentation work list (HBM): a candidate (diff, age, seq, idx, channel | position << 9)
 // of the physical pass or a groom-eligible service (seq, idx) of the grooming pass
-struct OrlgPhyCand { double diff, age; uint32_t seq; uint16_t idx, chj; };
-static_assert(sizeof(OrlgPhyCand) == 24, "OrlgPhyCand layout");
+struct OrlgPhyCand { double diff, age; uint32_t seq; uint16_t idx, chj; uint16_t gid, pad0; uint32_t pad1; };
+static_assert(sizeof(OrlgPhyCand) == 32, "OrlgPhyCand layout");
 #define ORLG_CS_MAX 64             // entries per channel_state[src, dst, k-path] list: p.cs_len <= one wavefront
 // one channel_state tuple (channel, used, free, capacity), 100 Gb/s units: ch | used << 9 | free << 14 | cap << 19 | 1 << 31
 DEV uint32_t cs_pack(int ch, int used, int free_, int cap) {
@@ -84,6 +84,11 @@ struct OrlgPhyParams {
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
         t_plen, t_pathpair, t_masks;
     int32_t use_masks, pad_masks;   // E <= 32: link sets as 32-bit masks (OrlgPathMasks) instead of the adjacency CSR
+    // cut metric through per-node free degrees (orlg_phy_config::path_node_weights), networks of at most 16 nodes
+    uint4 *nv;              // [B][cpad] D[channel]: byte v = links at node v that are free on the channel
+    const uint4 *nvrec;     // [num_paths][2] node weights c (16 bytes) | wsum, cq (int16), chords
+    uint4 deg;              // links per node
+    int32_t use_nv, pad_nv;
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
     const double *gsnr_t;   // [num_rows*K][cpad]
     // per-call IO
@@ -223,6 +228,49 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
     (void)want_cuts;
 }
 
+// ---- the cut metric through per-node free degrees (OrlgPhyParams::nv).  A path's record: c (16 node weights), wsum = sum of
+// its adjacency weights, cq = c . (path links per node), its chords (links between two path nodes that are not path links).
+struct NvRec { uint4 c; int wsum, cq, nchord; uint32_t cl_lo, cl_hi, cw_lo, cw_hi; };   // chord links / weights: bytes
+DEV NvRec nv_load(const uint4 *nvrec, int gid) {
+    const uint4 a = nvrec[2 * gid], b = nvrec[2 * gid + 1];
+    NvRec r;
+    r.c = a;
+    r.wsum = (int)(int16_t)(b.x & 0xffffu); r.cq = (int)(int16_t)(b.x >> 16);
+    r.nchord = (int)(b.y & 0xffu);
+    // bytes 21..25 chord links, 26..30 chord weights
+    r.cl_lo = (b.y >> 8) | (b.z << 24); r.cl_hi = (b.z >> 8) & 0xffu;                 // links 0..3 | link 4
+    r.cw_lo = (b.z >> 16) | (b.w << 16); r.cw_hi = (b.w >> 16) & 0xffu;               // weights 0..3 | weight 4
+    return r;
+}
+DEV int nv_dot(const uint4 &c, const uint4 &d) {
+    uint32_t s = __builtin_amdgcn_udot4(c.x, d.x, 0u, false);
+    s = __builtin_amdgcn_udot4(c.y, d.y, s, false);
+    s = __builtin_amdgcn_udot4(c.z, d.z, s, false);
+    return (int)__builtin_amdgcn_udot4(c.w, d.w, s, false);
+}
+// weighted free chords of the record on channel ch
+DEV int nv_chords(const u64 *occ, const NvRec &r, int ch, int W) {
+    int s = 0;
+    for (int q = 0; q < r.nchord; ++q) {
+        const int cl = (int)((q < 4 ? r.cl_lo >> (8 * q) : r.cl_hi) & 0xffu), cw = (int)((q < 4 ? r.cw_lo >> (8 * q) : r.cw_hi) & 0xffu);
+        s += cw * (int)((occ[__mul24(cl, W) + (ch >> 6)] >> (ch & 63)) & 1ull);
+    }
+    return s;
+}
+// D[ch] += c (the channel is returned on the path) or -= c (taken): bytes never carry into their neighbours, a node has at
+// least c[v] free / used links among the path's own
+DEV void nv_update(uint4 *nv, const uint4 &c, int ch, bool returned) {
+    uint4 d = nv[ch];
+    if (returned) { d.x += c.x; d.y += c.y; d.z += c.z; d.w += c.w; }
+    else { d.x -= c.x; d.y -= c.y; d.z -= c.z; d.w -= c.w; }
+    nv[ch] = d;
+}
+// a wave reads D entries other lanes of it wrote: the stores have to be complete (same CU: workgroup scope is enough)
+DEV void nv_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Level and fragmentation metric of the lane's channel in every word of candidate path `idp` (level -1: not free).
 //   cut (calculate_r_cut modified, phy_rmsa_env.py:1140-1193): for a channel free on the path the "cuts before minus
 //   cuts after" against the links adjacent to the path's nodes reduce to  sum_j weight_j * (1 - 2 * available[link_j]);
@@ -231,7 +279,8 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
 template <int W>
 DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, const uint8_t *mrow,
                          int lane, int metric_mode /* 0 cut, 1 rss, 2 none */, bool flat_level, int (&lv)[W], double (&mt)[W],
-                         const uint32_t (&cols)[W], const double *r0w /* LDS [W][64]: RSS of the lane's columns as they are */) {
+                         const uint32_t (&cols)[W], const double *r0w /* LDS [W][64]: RSS of the lane's columns as they are */,
+                         const uint4 (&dv)[W] /* D of the lane's channels (cut metric with node-degree vectors) */) {
     if (p.use_masks && metric_mode == 1) {
         // the columns and their RSS as they are were built once for all candidate paths: phy_columns
         const uint32_t pmask = (uint32_t)uni((int)tb.masks[gid].path);
@@ -245,6 +294,22 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
                 const double metric = rss_of_column(cols[w] & ~pmask, tb.sqrt_tab) - r0w[w * 64 + lane];
                 if (fr) { lv[w] = flat_level ? 0 : (int)mrow[ch]; mt[w] = metric; }
             }
+        }
+        return;
+    }
+    if (metric_mode == 0 && p.use_nv) {
+        // cut metric = wsum - 2 * (c . D[channel] - cq - free chords): four byte dot products per channel; the caller fetched D
+        // of the lane's W channels once for all candidate paths
+        const NvRec nr = nv_load(p.nvrec, gid);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const u64 x = readlane64(acc, idp * W + w);
+            const int ch = 64 * w + lane;
+            const bool fr = ((x >> lane) & 1ull) && ch < p.C;
+            lv[w] = -1; mt[w] = 0.0;
+            int s = nv_dot(nr.c, dv[w]) - nr.cq;
+            if (nr.nchord) s -= nv_chords(occ, nr, ch, W);
+            if (fr) { lv[w] = flat_level ? 0 : (int)mrow[ch]; mt[w] = (double)(nr.wsum - 2 * s); }
         }
         return;
     }
@@ -496,6 +561,29 @@ DEV double wave_min_key(uint32_t key, bool has) {
     return m >= none ? -1.0 : m;
 }
 
+// The two scans of the defragmentation walk all running services, 48-byte records in HBM, through an LDS staging area (a
+// chunk of records, coalesced 16-byte loads, then one record per lane).  The next chunk is requested into registers before
+// the current one is worked on, so that the scan does not wait for HBM once per chunk.
+struct SvcPrefetch { uint4 v[3]; };
+DEV void svc_fetch(SvcPrefetch &pf, const OrlgPhySvc *grec, int i0, int n_running, int chunk, int lane) {
+    const int cnt = n_running - i0 < chunk ? n_running - i0 : chunk;
+    const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * k;
+        pf.v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (q < cnt * 3) pf.v[k] = src[q];
+    }
+}
+DEV void svc_stash(const SvcPrefetch &pf, OrlgPhySvc *stage, int cnt, int lane) {
+    uint4 *dst = reinterpret_cast<uint4 *>(stage);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int q = lane + 64 * k;
+        if (q < cnt * 3) dst[q] = pf.v[k];
+    }
+}
+
 // The periodic defragmentation of PhyRMSAEnv.step (phy_rmsa_env.py:355-417), run when services_processed is a multiple of
 // defrag_period, right after _next_service.  Two passes:
 //  1. _groom_defragmentation (:703-733): a service that is the ONLY user of a partially used channel moves that share
@@ -511,7 +599,7 @@ DEV double wave_min_key(uint32_t key, bool has) {
 template <int W>
 DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
                              uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
-                             int &next_seq, double current_time, int req_src, int req_dst, int lane SEC_PARAMS) {
+                             int &next_seq, double current_time, int req_src, int req_dst, int lane, uint4 *gnv SEC_PARAMS) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
@@ -521,14 +609,14 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     OrlgPhySvc *stage = reinterpret_cast<OrlgPhySvc *>(r0w);
     // ------------------------------------------------------------------ 1. grooming pass
     int n_el = 0;
+    static_assert(CHUNK * 3 <= 192, "three 16-byte rows per lane");
+    SvcPrefetch pf;
+    if (n_running > 0) svc_fetch(pf, grec, 0, n_running, CHUNK, lane);
     for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
         const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
-            uint4 *dst = reinterpret_cast<uint4 *>(stage);
-            for (int q = lane; q < cnt * 3; q += 64) dst[q] = src[q];
-        }
+        svc_stash(pf, stage, cnt, lane);
         wave_sync();
+        if (i0 + CHUNK < n_running) svc_fetch(pf, grec, i0 + CHUNK, n_running, CHUNK, lane);   // in flight during this chunk
         const int idx = i0 + lane;
         bool elig = false;
         uint32_t seq = 0;
@@ -540,14 +628,24 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
             for (int j = 0; j < nch; ++j) any_partial = any_partial || (r->ch[j] & (1 << 14));
             if (any_partial) {
                 const int key = svc_key(tb, N, K, gid, r->flags);
-                const int n = gcs_n[key];
                 const uint32_t *lst = gcs + (size_t)key * p.cs_len;
+                // the list's length and its first eight entries are requested together (cs_len is a power of two >= 8): one
+                // HBM round trip for nearly every list
+                const int n = gcs_n[key];
+                const uint4 e03 = reinterpret_cast<const uint4 *>(lst)[0], e47 = reinterpret_cast<const uint4 *>(lst)[1];
+                const uint32_t e8[8] = {e03.x, e03.y, e03.z, e03.w, e47.x, e47.y, e47.z, e47.w};
                 for (int j = 0; j < nch && !elig; ++j) {
                     const int raw = r->ch[j];
                     if (raw & (1 << 14)) {
                         const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
                         bool sole = false, target = false;
-                        for (int t = 0; t < n; t += 4) {  // four independent loads per round trip
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (t < n) {
+                                if (cs_ch(e8[t]) == ch) sole = sole || cs_used(e8[t]) == mine;
+                                else target = target || cs_free(e8[t]) >= mine;
+                            }
+                        for (int t = 8; t < n; t += 4) {  // four independent loads per round trip
                             uint32_t en[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) en[q] = t + q < n ? lst[t + q] : 0u;
@@ -611,6 +709,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                             cs_store(gcs, gcs_n, key, l, lane);
                             // _move_virtual (:735-764): the old channel goes dark on the path, the list entry moves to the end
                             if (lane < rec->hops) occ[(int)rec->link[lane] * W + (ch >> 6)] |= 1ull << (ch & 63);
+                            if (gnv && lane == 0) nv_update(gnv, p.nvrec[2 * gid], ch, true);
                             wave_sync();
                             const int nxt = (lane >= j && lane + 1 < nch) ? lch[lane + 1] : 0;
                             wave_sync();
@@ -657,14 +756,13 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     SEC(12);  // defragmentation: candidate scan
     if (gmoves <= p.number_moves) {
         int nc = 0;
+        if (gnv) nv_fence();   // the grooming pass may have returned channels
+        if (n_running > 0) svc_fetch(pf, grec, 0, n_running, CHUNK, lane);
         for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
             const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
-                uint4 *dst = reinterpret_cast<uint4 *>(stage);
-                for (int q = lane; q < cnt * 3; q += 64) dst[q] = src[q];
-            }
+            svc_stash(pf, stage, cnt, lane);
             wave_sync();
+            if (i0 + CHUNK < n_running) svc_fetch(pf, grec, i0 + CHUNK, n_running, CHUNK, lane);   // in flight during this chunk
             const int idx = i0 + lane;
             const bool act = lane < cnt;
             const OrlgPhySvc *r = stage + (act ? lane : 0);
@@ -681,7 +779,18 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     const int raw = (int)r->ch[j];
                     if (!(raw & (1 << 14))) {  // only channels the service fills are reallocated
                         ch = raw & 0x1ff;
-                        diff = rss ? lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1, p.use_masks ? tb.masks + my_gid : nullptr) : (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
+                        if (rss) {
+                            diff = lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1, p.use_masks ? tb.masks + my_gid : nullptr);
+                        } else if (gnv) {
+                            // the service holds the channel on its whole path: c . D[ch] counts the free links towards
+                            // off-path nodes and the free chords; gain of releasing = 2 * (that - chords) - wsum
+                            const NvRec nr = nv_load(p.nvrec, my_gid);
+                            int s = nv_dot(nr.c, gnv[ch]);
+                            if (nr.nchord) s -= nv_chords(occ, nr, ch, W);
+                            diff = (double)(2 * s - nr.wsum);
+                        } else {
+                            diff = (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
+                        }
                         is_c = diff > 0.0;
                     }
                 }
@@ -691,6 +800,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     if (is_c && pos < p.cand_cap) {
                         OrlgPhyCand c;
                         c.diff = diff; c.age = current_time - my_arrival; c.seq = my_seq; c.idx = (uint16_t)idx; c.chj = (uint16_t)(ch | (j << 9));
+                        c.gid = (uint16_t)my_gid; c.pad0 = 0; c.pad1 = 0u;
                         cand[pos] = c;
                     }
                     nc += popc64(m);
@@ -701,56 +811,109 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
         wave_sync();
         SEC(14);  // defragmentation: candidate rounds
+        // The rounds are sequential (a move changes what the next candidate sees) and each used to pay half a dozen dependent HBM
+        // round trips.  The candidates' sort keys never change once scanned, so they are fetched ONCE into registers -- lane l
+        // holds candidates l and l + 64 (a defragmentation of the load-1400 workload has ~100) -- and a round picks the next one
+        // with three wave reductions; the service record is only read when a move actually happens, and the six reads of the
+        // QoT table a round needs (the candidate's level + the level of every channel) are in flight together.
+        constexpr int RC = 2;                      // register-resident candidates per lane
+        const bool in_regs = nc <= 64 * RC;
+        double rd[RC], ra[RC];
+        u64 ro[RC];
+        uint32_t rx[RC], rg[RC];                   // idx | chj << 16, path record
+#pragma unroll
+        for (int s = 0; s < RC; ++s) {
+            rd[s] = -1.0; ra[s] = 0.0; ro[s] = ~0ull; rx[s] = 0u; rg[s] = 0u;
+            const int c = lane + 64 * s;
+            if (in_regs && c < nc) {
+                rd[s] = cand[c].diff; ra[s] = cand[c].age;
+                ro[s] = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
+                rx[s] = (uint32_t)cand[c].idx | ((uint32_t)cand[c].chj << 16);
+                rg[s] = (uint32_t)cand[c].gid;
+            }
+        }
+        const int base_cur = tb.pair_base[req_src * N + req_dst];
+        // D of the lane's channels stays in registers over the rounds; a move patches the two entries it rewrote
+        uint4 dv[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) dv[w] = make_uint4(0u, 0u, 0u, 0u);
+        if (gnv && !rss) {
+            nv_fence();
+#pragma unroll
+            for (int w = 0; w < W; ++w) dv[w] = gnv[64 * w + lane];
+        }
         for (int round = 0; round < nc; ++round) {  // every round retires one candidate
             // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
             double bd = -1.0, ba = 0.0;
             u64 bo = ~0ull;
             int bc = -1;
-            for (int c = lane; c < nc; c += 64) {
-                const double d = cand[c].diff, a = cand[c].age;
-                const u64 o = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
-                if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = c; }
+            if (in_regs) {
+#pragma unroll
+                for (int s = 0; s < RC; ++s) {
+                    const double d = rd[s], a = ra[s];
+                    const u64 o = ro[s];
+                    if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = s; }
+                }
+            } else {
+                for (int c = lane; c < nc; c += 64) {
+                    const double d = cand[c].diff, a = cand[c].age;
+                    const u64 o = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
+                    if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = c; }
+                }
             }
             // lexicographic maximum over the lanes' bests: greatest diff, then greatest age, then lowest order key (36 bits: exact
-            // as a double); the lane that holds it hands out the candidate index
+            // as a double); the lane that holds it hands out the candidate
+            double diff = 0.0;
+            int idx = 0, ch = 0, gid = 0;
             {
                 const double ninf = -__longlong_as_double((long long)ORLG_INF_BITS);
                 const double D = wave_max_f64(bc >= 0 ? bd : ninf);
-                if (!(D > 0.0)) { bc = -1; }
-                else {
-                    const double A = wave_max_f64((bc >= 0 && bd == D) ? ba : ninf);
-                    const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
-                    const u64 wm = ballot(bc >= 0 && bd == D && ba == A && (double)bo == O);
-                    bc = __builtin_amdgcn_readlane(bc, ctz64(wm));
+                if (!(D > 0.0)) break;
+                const double A = wave_max_f64((bc >= 0 && bd == D) ? ba : ninf);
+                const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
+                const int wl = ctz64(ballot(bc >= 0 && bd == D && ba == A && (double)bo == O));
+                diff = D;
+                if (in_regs) {
+                    uint32_t x = 0u, gx = 0u;
+#pragma unroll
+                    for (int s = 0; s < RC; ++s)
+                        if (bc == s) { x = rx[s]; gx = rg[s]; }
+                    x = (uint32_t)__builtin_amdgcn_readlane((int)x, wl);
+                    idx = (int)(x & 0xffffu); ch = (int)((x >> 16) & 0x1ffu);
+                    gid = __builtin_amdgcn_readlane((int)gx, wl);
+                    if (lane == wl) {
+#pragma unroll
+                        for (int s = 0; s < RC; ++s)
+                            if (bc == s) rd[s] = -1.0;   // retired
+                    }
+                } else {
+                    const int cb = __builtin_amdgcn_readlane(bc, wl);
+                    idx = uni((int)cand[cb].idx); ch = uni((int)(cand[cb].chj & 0x1ff)); gid = uni((int)cand[cb].gid);
+                    wave_sync();
+                    if (lane == 0) cand[cb].diff = -1.0;
                 }
             }
-            bc = uni(bc);
-            if (bc < 0) break;
-            const double diff = cand[bc].diff;
-            const int idx = uni((int)cand[bc].idx), ch = uni((int)(cand[bc].chj & 0x1ff));
-            wave_sync();
-            if (lane == 0) cand[bc].diff = -1.0;
             const OrlgPhySvc *r = grec + idx;
-            const int gid = uni((int)r->gid), nch = uni((int)r->nch);
-            const int mych = lane < nch ? (int)r->ch[lane] : 0xffff;
-            const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
-            if (jm) {
-                const int j = ctz64(jm);
+            {
                 const OrlgPathRec *rec = tb.recs + gid;
                 const int row = tb.pair_row[tb.path_pair[gid]];
                 // the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): right
                 // when both serve the same node pair, otherwise its loop runs out and leaves k - 1
-                const int base_cur = tb.pair_base[req_src * N + req_dst];
                 const int idp = (gid >= base_cur && gid < base_cur + K) ? gid - base_cur : K - 1;
                 const uint8_t *mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
-                const int level = uni((int)mrow[ch]);
+                // one trip: the candidate's level and the level of every channel
+                const int level_l = (int)mrow[ch];
+                int lev_w[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) lev_w[w] = (int)mrow[64 * w + lane];
+                const int level = uni(level_l);
                 u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
                 // only channels of the candidate's modulation level can take it over: words without one are not scored
                 {
                     u64 mine = 0ull;
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
-                        const u64 same = ballot((int)mrow[64 * w + lane] == level);
+                        const u64 same = ballot(lev_w[w] == level);
                         if (lane == w) mine = same;
                     }
                     acc &= mine;
@@ -759,28 +922,42 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 double mtr[W];
                 uint32_t cols[W];
                 phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
-                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, false, lv, mtr, cols, r0w);
-#pragma unroll
-                for (int w = 0; w < W; ++w) lv[w] = lv[w] == level ? 0 : -1;
+                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv);
                 int l0, c0;
                 double m0;
                 phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
                 if (l0 >= 0 && -1.0 * m0 < diff) {
-                    // _move (:662-697)
-                    if (lane < rec->hops) {
-                        u64 *rowp = occ + (int)rec->link[lane] * W;
-                        rowp[c0 >> 6] &= ~(1ull << (c0 & 63));
-                        rowp[ch >> 6] |= 1ull << (ch & 63);
+                    // _move (:662-697): the service's channel list is read now -- the moved entry goes to its end
+                    const int nch = uni((int)r->nch);
+                    const int mych = lane < nch ? (int)r->ch[lane] : 0xffff;
+                    const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
+                    if (jm) {
+                        const int j = ctz64(jm);
+                        if (lane < rec->hops) {
+                            u64 *rowp = occ + (int)rec->link[lane] * W;
+                            rowp[c0 >> 6] &= ~(1ull << (c0 & 63));
+                            rowp[ch >> 6] |= 1ull << (ch & 63);
+                        }
+                        if (gnv) {
+                            const uint4 cv = p.nvrec[2 * gid];
+                            if (lane < 2) nv_update(gnv, cv, lane == 0 ? c0 : ch, lane != 0);
+#pragma unroll
+                            for (int w = 0; w < W; ++w) {   // the register copies of the two entries
+                                const int cc = 64 * w + lane;
+                                if (cc == c0) { dv[w].x -= cv.x; dv[w].y -= cv.y; dv[w].z -= cv.z; dv[w].w -= cv.w; }
+                                if (cc == ch) { dv[w].x += cv.x; dv[w].y += cv.y; dv[w].z += cv.z; dv[w].w += cv.w; }
+                            }
+                        }
+                        const int nxt = __shfl_down(mych, 1);
+                        int nv = mych;
+                        if (lane >= j && lane + 1 < nch) nv = nxt;
+                        if (lane == nch - 1) nv = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
+                        if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv;
+                        if (lane == 0) grec[idx].seq = (uint32_t)next_seq;
+                        next_seq += 1;
+                        cmoves += 1;
+                        wave_sync();
                     }
-                    const int nxt = __shfl_down(mych, 1);
-                    int nv = mych;
-                    if (lane >= j && lane + 1 < nch) nv = nxt;
-                    if (lane == nch - 1) nv = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
-                    if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv;
-                    if (lane == 0) grec[idx].seq = (uint32_t)next_seq;
-                    next_seq += 1;
-                    cmoves += 1;
-                    wave_sync();
                 }
             }
             if (cmoves + gmoves > p.number_moves) break;
@@ -854,6 +1031,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     nb.horizon = -__longlong_as_double((long long)ORLG_INF_BITS);  // the first look at the queue rebuilds the buffer
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
+    uint4 *gnv = p.use_nv ? p.nv + (size_t)env * p.cpad : nullptr;   // node-degree vectors of the cut metric
 
     SEC(1);  // state load
     // ------------------------------------------------------------------ HBM -> LDS
@@ -893,6 +1071,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy: virtual layer
         if (p.mode == ORLG_MODE_STEP) {
+            // D of the lane's channels (cut metric): requested first, used after the virtual-layer check; it serves every candidate
+            // path of the request.  (The fence: entries other lanes rewrote since the last look -- their stores are long done.)
+            uint4 dv[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) dv[w] = make_uint4(0u, 0u, 0u, 0u);
+            if (gnv && (p.policy == ORLG_PHY_POLICY_BMFA_CUT || p.policy == ORLG_PHY_POLICY_FAFF)) {
+                nv_fence();
+#pragma unroll
+                for (int w = 0; w < W; ++w) dv[w] = gnv[64 * w + lane];
+            }
             const int base = tb.pair_base[req_src * N + req_dst];
             const int row = tb.pair_row[req_src * N + req_dst];
             const int demand = tb.bit_rates[req_br];
@@ -975,7 +1163,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         if (idp < K) {
                             int lv[W];
                             double mtr[W];
-                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr, cols, r0w);
+                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
                             int bl, bc;
                             double bm;
                             phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
@@ -1010,7 +1198,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             for (int w = 0; w < W; ++w) { lv[w] = keep_lv[w]; mtr[w] = keep_mt[w]; }
                             keep_idp = -1;
                         } else {
-                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w);
+                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
                         }
                         int unassigned = demand;
                         nsel = 0;
@@ -1112,6 +1300,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             const int ch = sel_ch[ci];
                             rowp[ch >> 6] &= ~(1ull << (ch & 63));
                         }
+                    }
+                    if (gnv) {   // the nodes of the path lose free links on these channels
+                        const uint4 cv = p.nvrec[2 * gid];
+                        if (lane < nsel) nv_update(gnv, cv, sel_ch[lane], false);
                     }
                     // partially used channels enter channel_state (:600-602)
                     {
@@ -1316,6 +1508,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
 #pragma unroll
                     for (int w = 0; w < W; ++w) rowp[w] |= freemask[w];
                 }
+                if (gnv) {   // the returned channels: lane = channel of word w, the nodes of the path gain free links
+                    const uint4 cv = p.nvrec[2 * (int)sv.gid];
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        if (freemask[w] != 0ull && ((freemask[w] >> lane) & 1ull)) nv_update(gnv, cv, 64 * w + lane, true);
+                }
                 // swap-remove: the last live entry takes the victim's place (its near-buffer entry follows it) ...
                 n_running -= 1;
                 if (victim != n_running) {
@@ -1342,7 +1540,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             wave_sync();
             const long long processed = ws->c[0];
             if (processed % p.defrag_period == 0)
-                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane SEC_ARGS);
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv SEC_ARGS);
         }
 
         if (p.mode == ORLG_MODE_STEP) {

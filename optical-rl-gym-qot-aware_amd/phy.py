@@ -120,6 +120,13 @@ class BatchedPhyRMSAEnv:
         cc.modulation_level = keep(mod, np.uint8)
         cc.gsnr = keep(gs, np.float64)
         cc.adj_off, cc.adj_link, cc.adj_weight = keep(adj_off, np.int32), keep(adj_link, np.int32), keep(adj_weight, np.int32)
+        # the cut metric as byte dot products over per-node free degrees (networks of at most 16 nodes); ORLG_PHY_NODEVEC=0
+        # keeps the adjacency-list evaluation (identical results: tests/test_gpu_phy.py runs both)
+        import os
+        nv = t.cut_node_tables() if os.environ.get("ORLG_PHY_NODEVEC", "1") != "0" else None
+        self.node_vectors = nv is not None
+        if nv is not None:
+            cc.path_node_weights, cc.node_degree = keep(nv[0], np.uint8), keep(nv[1], np.uint8)
         seeds_ptr = None
         if seeds is not None:
             seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

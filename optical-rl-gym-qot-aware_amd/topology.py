@@ -215,6 +215,61 @@ class FrozenTopology:
             off.append(len(links))
         return np.asarray(off, np.int32), np.asarray(links, np.int32), np.asarray(weights, np.int32)
 
+    def cut_node_tables(self):
+        """The cut metric through per-node free degrees (networks of at most 16 nodes).
+
+        ``calculate_r_cut(modified=True)`` sums, over the links that join a path node to a node OFF the path, weight x
+        (1 - 2 x available) with weight 1 at the path's end nodes and 2 inside (:meth:`cut_adjacency`).  With
+        ``D[v, ch]`` = number of links at node ``v`` that are free on channel ``ch`` this is a dot product:
+
+            sum_j w_j * available_j  =  c . D[:, ch]  -  (the path's own links, if free)  -  (chords, if free)
+
+        where ``c[v]`` = 1 / 2 / 0 (end / interior / off-path node) and a chord is a link between two path nodes that is not
+        a path link (weight ``c[u] + c[v]``).  When a channel is taken or returned on a whole path, ``D[:, ch]`` changes by
+        exactly ``c`` (a node loses one free link per path link it touches).  Returns ``(records [num_paths, 32] uint8,
+        degree [16] uint8)`` or ``None`` when the network does not fit (more than 16 nodes, a path with more than 5 chords).
+        Record: bytes 0..15 ``c``, 16..17 sum of the adjacency weights (int16), 18..19 ``c . (path links per node)``
+        (int16), 20 number of chords, 21..25 chord links, 26..30 chord weights."""
+        N = self.num_nodes
+        if N > 16 or self.num_links > 255:
+            return None
+        link_of, nbrs = {}, [[] for _ in range(N)]
+        deg = np.zeros(16, np.uint8)
+        for l, (a, b) in enumerate(self.link_ends):
+            link_of[int(a), int(b)] = l
+            link_of[int(b), int(a)] = l
+            nbrs[int(a)].append(int(b))
+            nbrs[int(b)].append(int(a))
+            deg[int(a)] += 1
+            deg[int(b)] += 1
+        rec = np.zeros((self.num_paths, 32), np.uint8)
+        for g in range(self.num_paths):
+            nodes = [int(x) for x in self.path_nodes[self.path_node_off[g]:self.path_node_off[g + 1]]]
+            on_path = set(nodes)
+            c = {n: (1 if i in (0, len(nodes) - 1) else 2) for i, n in enumerate(nodes)}
+            path_links = {link_of[nodes[i], nodes[i + 1]] for i in range(len(nodes) - 1)}
+            wsum, chords = 0, {}
+            for n in nodes:
+                for nk in nbrs[n]:
+                    if nk not in on_path:
+                        wsum += c[n]
+                    else:
+                        l = link_of[n, nk]
+                        if l not in path_links:
+                            chords[l] = c[n] + c[nk]
+            if len(chords) > 5:
+                return None
+            for n in nodes:
+                rec[g, n] = c[n]
+            cq = sum(c[nodes[i]] + c[nodes[i + 1]] for i in range(len(nodes) - 1))
+            rec[g, 16:18] = np.frombuffer(np.int16(wsum).tobytes(), np.uint8)
+            rec[g, 18:20] = np.frombuffer(np.int16(cq).tobytes(), np.uint8)
+            rec[g, 20] = len(chords)
+            for q, (l, w) in enumerate(sorted(chords.items())):
+                rec[g, 21 + q] = l
+                rec[g, 26 + q] = w
+        return rec, deg
+
     def pair_table_rows(self, pairs):
         """[N*N] row of the QoT tables for every ordered node pair: first row whose (source, destination)
         node numbers match in either order (``phy_rmsa_env.py:562-565``); -1 where none does."""

@@ -28,7 +28,7 @@ def make_env(topo, tables, kw, batch, **extra):
                                        ("phy_us14_s10_faff", 600), ("phy_us14_s15_faff_rss_load2400", 800),
                                        ("phy_us14_s10_bmfa_defrag_cut", 600), ("phy_us14_s10_bmfa_rss_defrag_rss", 450),
                                        ("phy_us14_s16_sapff_defrag_load3000", 700), ("phy_jpn12_s7_bmff_defrag_rss", 500)])
-def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
+def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle, expect_node_vectors=True):
     z, meta = load_golden(case)
     topo = load_topology(meta["topology"])
     tables = load_phy_tables(meta["tables"])
@@ -36,6 +36,7 @@ def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
     n, batch = min(nmax, meta["steps"]), 4
     env = make_env(topo, tables, kw, batch)
     assert env.grooming == kw.get("grooming", False)
+    assert env.node_vectors == expect_node_vectors
     policy = meta["policy"]
     tr = env.run(policy, n, outputs=OUTS, auto_reset=True)
     cnt, now, nrun, av, est = env.counters(), env.current_time(), env.num_running(), env.available_channels(), env.episode_stats()
@@ -78,6 +79,16 @@ def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle):
         assert np.array_equal(dc[:, 0] / 2 + dc[:, 1], z["num_moves"][:n])
         assert np.array_equal(dc[:, 1], z["num_moves_groom"][:n]) and np.array_equal(dc[:, 2], z["num_defrag_cycle"][:n])
     env.close()
+
+
+@pytest.mark.parametrize("case,nmax", [("phy_us14_s10_bmfa", 500), ("phy_us14_s10_bmfa_defrag_cut", 400), ("phy_us14_s10_faff", 400),
+                                       ("phy_jpn12_s5_bmff", 300)])
+def test_phy_cut_metric_by_adjacency_lists(case, nmax, device_log_in_oracle, monkeypatch):
+    """The cut metric has two evaluations on the device: byte dot products over per-node free degrees (networks of at most 16
+    nodes: the default for US14 / JPN12) and the adjacency lists of calculate_r_cut itself (any network).  The suite above
+    runs the first; ORLG_PHY_NODEVEC=0 forces the second, held to the same oracle and reference traces."""
+    monkeypatch.setenv("ORLG_PHY_NODEVEC", "0")
+    test_phy_policy_vs_oracle_and_reference(case, nmax, None, expect_node_vectors=False)
 
 
 def test_phy_info_ratios_match_reference(device_log_in_oracle):
