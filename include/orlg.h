@@ -247,7 +247,9 @@ typedef struct orlg_phy_config {
      * to the occupancy (it changes by exactly c when a channel is taken or returned on a path) and evaluates the metric with
      * byte dot products.  path_node_weights: [num_paths][32] records -- bytes 0..15 c, 16..17 sum of the adjacency weights
      * (int16), 18..19 c . (path links per node) (int16), 20 number of chords (<= 5), 21..25 chord links, 26..30 chord
-     * weights; node_degree: [16] links per node.  NULL = adjacency lists only (identical results). */
+     * weights; node_degree: [16] links per node.  NULL = adjacency lists only (identical results).  D lives in HBM (L2) and
+     * costs a step one read-after-write round trip, so the library uses it when the periodic defragmentation is on (hundreds
+     * of evaluations per cycle) and the LDS adjacency lists otherwise. */
     const uint8_t *path_node_weights, *node_degree;
 } orlg_phy_config;
 

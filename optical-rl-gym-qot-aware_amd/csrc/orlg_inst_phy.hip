@@ -9,4 +9,6 @@
 #define ORLG_CAT2(a, b) a##b
 #define ORLG_CAT(a, b) ORLG_CAT2(a, b)
 
-orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)() { return orlg_phy_kernel<ORLG_INST_W>; }
+orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)(int defragmentation) {
+    return defragmentation ? orlg_phy_kernel<ORLG_INST_W, true> : orlg_phy_kernel<ORLG_INST_W, false>;
+}

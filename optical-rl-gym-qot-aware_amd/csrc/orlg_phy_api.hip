@@ -30,9 +30,9 @@ static int phy_sync_check(orlg_phy_env *e) {
 }
 
 typedef orlg_phy_kernel_t phy_kernel_t;
-static phy_kernel_t pick_phy(int W) {
+static phy_kernel_t pick_phy(int W, int defragmentation) {
     switch (W) {
-#define X(n) case n: return orlg_phy_kernel_W##n ? orlg_phy_kernel_W##n() : nullptr;
+#define X(n) case n: return orlg_phy_kernel_W##n ? orlg_phy_kernel_W##n(defragmentation) : nullptr;
         ORLG_FOR_EACH_PHY_W(X)
 #undef X
         default: return nullptr;
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
 }
 
 static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
-    phy_kernel_t k = pick_phy(e->W);
+    const int df = (p.defrag_period > 0 || p.use_nv) ? 1 : 0;   // (use_nv without the defragmentation: ORLG_PHY_NODEVEC=2, tests)
+    phy_kernel_t k = pick_phy(e->W, df);
     if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
@@ -130,8 +131,8 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
-    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d> grid=%d block=%d lds=%zu", e->W, nblocks, ORLG_WAVE * wpb,
-             e->lds_block_bytes);
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d,%s> grid=%d block=%d lds=%zu", e->W,
+             df ? "true" : "false", nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 
@@ -390,7 +391,12 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     }
     // node-degree vectors of the cut metric (include/orlg.h, orlg_phy_config::path_node_weights): D[env][channel] = 16 bytes,
     // links free at every node; L2-resident, updated whenever a channel is taken or returned on a path
-    p.use_nv = (c->path_node_weights && c->node_degree && N <= 16) ? 1 : 0;
+    // (kept in HBM, D costs a step one read-after-write round trip: it pays where the defragmentation evaluates hundreds of
+    // (service, channel) pairs per cycle; without the defragmentation the adjacency lists in LDS are faster -- measured 207 vs
+    // 181 M env-steps/s on the US14 load-1400 workload; ORLG_PHY_NODEVEC=2 forces it on for tests)
+    const char *nvm = getenv("ORLG_PHY_NODEVEC");
+    const bool nv_force = nvm && nvm[0] == '2';
+    p.use_nv = (c->path_node_weights && c->node_degree && N <= 16 && (p.defrag_period > 0 || nv_force)) ? 1 : 0;
     if (p.use_nv) {
         TRY(alloc(reinterpret_cast<void **>(&p.nv), (size_t)batch * p.cpad * sizeof(uint4)));
         uint4 *d_rec = nullptr;
@@ -400,6 +406,7 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.nvrec = d_rec;
         memcpy(&p.deg, c->node_degree, 16);
     }
+    if (p.use_masks) TRY(alloc(reinterpret_cast<void **>(&p.cterm), (size_t)batch * p.cpad * sizeof(double)));   // (scratch, see OrlgPhyParams)
     if (p.defrag_period > 0) {
         // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
         p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;

@@ -89,6 +89,8 @@ struct OrlgPhyParams {
     const uint4 *nvrec;     // [num_paths][2] node weights c (16 bytes) | wsum, cq (int16), chords
     uint4 deg;              // links per node
     int32_t use_nv, pad_nv;
+    double *cterm;          // [B][cpad] scratch: per-channel term of calculate_total_r_spatial while a launch keeps the per-step
+                            // totals incrementally (not part of the state: rebuilt at the start of every launch that needs it)
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
     const double *gsnr_t;   // [num_rows*K][cpad]
     // per-call IO
@@ -180,7 +182,7 @@ DEV double rss_of_column(uint32_t col, const double *sqrt_tab) {
 // every channel's column along the link axis.  Lane = channel; the link loop is wave-uniform.
 template <int W>
 DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C, int lane, double *scratch_d, bool want_cuts,
-                            bool want_rss, bool use_masks, double &cuts_out, double &rss_out) {
+                            bool want_rss, bool use_masks, double &cuts_out, double &rss_out, int &total_runs_out) {
     int total_runs = 0;
     for (int w = 0; w < W; ++w) {
         const int ch = 64 * w + lane;
@@ -217,6 +219,7 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
         total_runs += runs;
     }
     cuts_out = (double)total_runs / (double)C;
+    total_runs_out = total_runs;
     if (want_rss) {
         wave_sync();
         // the reference accumulates the per-channel terms in channel order in float64 (phy_rmsa_env.py:1117)
@@ -257,13 +260,15 @@ DEV int nv_chords(const u64 *occ, const NvRec &r, int ch, int W) {
     }
     return s;
 }
-// D[ch] += c (the channel is returned on the path) or -= c (taken): bytes never carry into their neighbours, a node has at
-// least c[v] free / used links among the path's own
+// D[ch] += c (the channel is returned on the path) or -= c (taken): bytes never carry into their neighbours (a node has at
+// least c[v] free / used links among the path's own), so four 32-bit adds do it -- as atomics without return: nothing to
+// wait for, the next reader fences first (nv_fence)
 DEV void nv_update(uint4 *nv, const uint4 &c, int ch, bool returned) {
-    uint4 d = nv[ch];
-    if (returned) { d.x += c.x; d.y += c.y; d.z += c.z; d.w += c.w; }
-    else { d.x -= c.x; d.y -= c.y; d.z -= c.z; d.w -= c.w; }
-    nv[ch] = d;
+    uint32_t *d = reinterpret_cast<uint32_t *>(nv + ch);
+    if (c.x) atomicAdd(d + 0, returned ? c.x : 0u - c.x);
+    if (c.y) atomicAdd(d + 1, returned ? c.y : 0u - c.y);
+    if (c.z) atomicAdd(d + 2, returned ? c.z : 0u - c.z);
+    if (c.w) atomicAdd(d + 3, returned ? c.w : 0u - c.w);
 }
 // a wave reads D entries other lanes of it wrote: the stores have to be complete (same CU: workgroup scope is enough)
 DEV void nv_fence() {
@@ -561,6 +566,38 @@ DEV double wave_min_key(uint32_t key, bool has) {
     return m >= none ? -1.0 : m;
 }
 
+// ---- per-step totals kept incrementally (networks of at most 32 links).  _calculate_total_cuts (phy_rmsa_env.py:1195-1203)
+// is an integer count of free runs over all channel columns; calculate_total_r_spatial (:1110-1121) a float64 sum of one term
+// per channel IN CHANNEL ORDER.  Both change only in the columns a provision / release / move touches: every such site
+// subtracts the column's runs before it changes the occupancy and adds them back afterwards (mc_before / mc_after, wave
+// uniform: the column = one ballot over link lanes), and rewrites the column's term; the per-step output is then the integer
+// total and the ordered sum of the cached terms instead of a rebuild of all 268 columns.
+struct MetricCache {
+    bool on, want_rss;
+    int total_runs;
+    double *cterm;          // HBM [cpad]
+    const double *sqrt_tab;
+    int E, W;
+};
+DEV uint32_t mc_column(const u64 *occ, const MetricCache &mc, int ch, int lane) {
+    const bool bit = lane < mc.E && ((occ[__mul24(lane, mc.W) + (ch >> 6)] >> (ch & 63)) & 1ull);
+    return (uint32_t)ballot(bit);
+}
+DEV void mc_before(const u64 *occ, MetricCache &mc, int ch, int lane) {
+    if (!mc.on) return;
+    const uint32_t col = mc_column(occ, mc, ch, lane);
+    mc.total_runs -= __builtin_popcount(col & ~(col << 1));
+}
+DEV void mc_after(const u64 *occ, MetricCache &mc, int ch, int lane) {
+    if (!mc.on) return;
+    const uint32_t col = mc_column(occ, mc, ch, lane);
+    mc.total_runs += __builtin_popcount(col & ~(col << 1));
+    if (mc.want_rss) {
+        const double t = rss_of_column(col, mc.sqrt_tab);
+        if (lane == 0) mc.cterm[ch] = t;
+    }
+}
+
 // The two scans of the defragmentation walk all running services, 48-byte records in HBM, through an LDS staging area (a
 // chunk of records, coalesced 16-byte loads, then one record per lane).  The next chunk is requested into registers before
 // the current one is worked on, so that the scan does not wait for HBM once per chunk.
@@ -599,7 +636,7 @@ DEV void svc_stash(const SvcPrefetch &pf, OrlgPhySvc *stage, int cnt, int lane) 
 template <int W>
 DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
                              uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
-                             int &next_seq, double current_time, int req_src, int req_dst, int lane, uint4 *gnv SEC_PARAMS) {
+                             int &next_seq, double current_time, int req_src, int req_dst, int lane, uint4 *gnv, MetricCache &mc SEC_PARAMS) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
@@ -708,9 +745,11 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                             cs_append(l, cs_pack(cs_ch(tg), cs_used(tg) + mine, cs_free(tg) - mine, cs_cap(tg)), lane);
                             cs_store(gcs, gcs_n, key, l, lane);
                             // _move_virtual (:735-764): the old channel goes dark on the path, the list entry moves to the end
+                            mc_before(occ, mc, ch, lane);
                             if (lane < rec->hops) occ[(int)rec->link[lane] * W + (ch >> 6)] |= 1ull << (ch & 63);
                             if (gnv && lane == 0) nv_update(gnv, p.nvrec[2 * gid], ch, true);
                             wave_sync();
+                            mc_after(occ, mc, ch, lane);
                             const int nxt = (lane >= j && lane + 1 < nch) ? lch[lane + 1] : 0;
                             wave_sync();
                             if (lane >= j && lane + 1 < nch) lch[lane] = nxt;
@@ -811,25 +850,42 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
         wave_sync();
         SEC(14);  // defragmentation: candidate rounds
-        // The rounds are sequential (a move changes what the next candidate sees) and each used to pay half a dozen dependent HBM
-        // round trips.  The candidates' sort keys never change once scanned, so they are fetched ONCE into registers -- lane l
-        // holds candidates l and l + 64 (a defragmentation of the load-1400 workload has ~100) -- and a round picks the next one
-        // with three wave reductions; the service record is only read when a move actually happens, and the six reads of the
-        // QoT table a round needs (the candidate's level + the level of every channel) are in flight together.
+        // The rounds are sequential (a move changes what the next candidate sees), but the ORDER of the candidates is fixed once
+        // they are scanned -- sorted(key=(-diff, -age)), stable -- and a candidate's table data (its path's node weights, the
+        // modulation level of every channel on that path) do not depend on the moves either.  So: the candidates are fetched
+        // once into registers (lane l holds candidates l and l + 64; the load-1400 workload has ~100 per defragmentation), every
+        // candidate's rank in the sorted order is counted once (all pairs, the keys are distinct), round q takes the candidate
+        // of rank q, and the table reads of round q + 1 are in flight while round q is worked on.  The service record is only
+        // read when a move actually happens.  More than 128 candidates: the keys stay in HBM and a round searches them.
         constexpr int RC = 2;                      // register-resident candidates per lane
         const bool in_regs = nc <= 64 * RC;
         double rd[RC], ra[RC];
         u64 ro[RC];
         uint32_t rx[RC], rg[RC];                   // idx | chj << 16, path record
+        int rank[RC];
 #pragma unroll
         for (int s = 0; s < RC; ++s) {
-            rd[s] = -1.0; ra[s] = 0.0; ro[s] = ~0ull; rx[s] = 0u; rg[s] = 0u;
+            rd[s] = -1.0; ra[s] = 0.0; ro[s] = ~0ull; rx[s] = 0u; rg[s] = 0u; rank[s] = 0x7fffffff;
             const int c = lane + 64 * s;
             if (in_regs && c < nc) {
                 rd[s] = cand[c].diff; ra[s] = cand[c].age;
                 ro[s] = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
                 rx[s] = (uint32_t)cand[c].idx | ((uint32_t)cand[c].chj << 16);
                 rg[s] = (uint32_t)cand[c].gid;
+                rank[s] = 0;
+            }
+        }
+        if (in_regs) {
+#pragma unroll
+            for (int t = 0; t < RC; ++t) {
+                const int cnt = nc - 64 * t < 64 ? nc - 64 * t : 64;
+                for (int l = 0; l < cnt; ++l) {   // candidate (l, t) against every lane's own
+                    const double jd = readlane_d(rd[t], l), ja = readlane_d(ra[t], l);
+                    const u64 jo = readlane64(ro[t], l);
+#pragma unroll
+                    for (int s = 0; s < RC; ++s)
+                        rank[s] += (jd > rd[s] || (jd == rd[s] && (ja > ra[s] || (ja == ra[s] && jo < ro[s])))) ? 1 : 0;
+                }
             }
         }
         const int base_cur = tb.pair_base[req_src * N + req_dst];
@@ -842,90 +898,118 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
 #pragma unroll
             for (int w = 0; w < W; ++w) dv[w] = gnv[64 * w + lane];
         }
-        for (int round = 0; round < nc; ++round) {  // every round retires one candidate
-            // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
-            double bd = -1.0, ba = 0.0;
-            u64 bo = ~0ull;
-            int bc = -1;
-            if (in_regs) {
+        // one candidate's round data: who it is, and what the tables say about its path
+        struct RoundData { double diff; int idx, ch, gid, level_l; int lev_w[W]; uint4 nr0, nr1; const uint8_t *mrow; bool valid; };
+        auto pick = [&](int q, RoundData &o) {   // the candidate of rank q (in_regs) and the loads of its table data
+            o.valid = false;
+            if (q >= nc) return;
+            const u64 m0 = ballot(rank[0] == q), m1 = ballot(rank[1] == q);
+            if ((m0 | m1) == 0ull) return;
+            const int wl = ctz64(m0 ? m0 : m1);
+            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)(m0 ? rx[0] : rx[1]), wl);
+            o.gid = __builtin_amdgcn_readlane((int)(m0 ? rg[0] : rg[1]), wl);
+            o.diff = readlane_d(m0 ? rd[0] : rd[1], wl);
+            o.idx = (int)(x & 0xffffu); o.ch = (int)((x >> 16) & 0x1ffu);
+            o.valid = true;
+        };
+        auto fetch = [&](RoundData &o) {         // the reads of the QoT table and of the path's node weights, all in flight together
+            const int row = tb.pair_row[tb.path_pair[o.gid]];
+            // the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): right
+            // when both serve the same node pair, otherwise its loop runs out and leaves k - 1
+            const int idp = (o.gid >= base_cur && o.gid < base_cur + K) ? o.gid - base_cur : K - 1;
+            o.mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
+            o.level_l = (int)o.mrow[o.ch];
 #pragma unroll
-                for (int s = 0; s < RC; ++s) {
-                    const double d = rd[s], a = ra[s];
-                    const u64 o = ro[s];
-                    if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = s; }
-                }
+            for (int w = 0; w < W; ++w) o.lev_w[w] = (int)o.mrow[64 * w + lane];
+            o.nr0 = make_uint4(0u, 0u, 0u, 0u); o.nr1 = o.nr0;
+            if (gnv && !rss) { o.nr0 = p.nvrec[2 * o.gid]; o.nr1 = p.nvrec[2 * o.gid + 1]; }
+        };
+        RoundData cur;
+        cur.valid = false;
+        for (int round = 0; round < nc; ++round) {  // every round retires one candidate
+            if (in_regs) {
+                pick(round, cur);
+                if (!cur.valid) break;
+                fetch(cur);
             } else {
+                // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
+                double bd = -1.0, ba = 0.0;
+                u64 bo = ~0ull;
+                int bc = -1;
                 for (int c = lane; c < nc; c += 64) {
                     const double d = cand[c].diff, a = cand[c].age;
                     const u64 o = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
                     if (d > 0.0 && (d > bd || (d == bd && (a > ba || (a == ba && o < bo))))) { bd = d; ba = a; bo = o; bc = c; }
                 }
-            }
-            // lexicographic maximum over the lanes' bests: greatest diff, then greatest age, then lowest order key (36 bits: exact
-            // as a double); the lane that holds it hands out the candidate
-            double diff = 0.0;
-            int idx = 0, ch = 0, gid = 0;
-            {
+                // lexicographic maximum over the lanes' bests: greatest diff, then greatest age, then lowest order key (36 bits:
+                // exact as a double); the lane that holds it hands out the candidate
                 const double ninf = -__longlong_as_double((long long)ORLG_INF_BITS);
                 const double D = wave_max_f64(bc >= 0 ? bd : ninf);
                 if (!(D > 0.0)) break;
                 const double A = wave_max_f64((bc >= 0 && bd == D) ? ba : ninf);
                 const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
                 const int wl = ctz64(ballot(bc >= 0 && bd == D && ba == A && (double)bo == O));
-                diff = D;
-                if (in_regs) {
-                    uint32_t x = 0u, gx = 0u;
-#pragma unroll
-                    for (int s = 0; s < RC; ++s)
-                        if (bc == s) { x = rx[s]; gx = rg[s]; }
-                    x = (uint32_t)__builtin_amdgcn_readlane((int)x, wl);
-                    idx = (int)(x & 0xffffu); ch = (int)((x >> 16) & 0x1ffu);
-                    gid = __builtin_amdgcn_readlane((int)gx, wl);
-                    if (lane == wl) {
-#pragma unroll
-                        for (int s = 0; s < RC; ++s)
-                            if (bc == s) rd[s] = -1.0;   // retired
-                    }
-                } else {
-                    const int cb = __builtin_amdgcn_readlane(bc, wl);
-                    idx = uni((int)cand[cb].idx); ch = uni((int)(cand[cb].chj & 0x1ff)); gid = uni((int)cand[cb].gid);
-                    wave_sync();
-                    if (lane == 0) cand[cb].diff = -1.0;
-                }
+                const int cb = __builtin_amdgcn_readlane(bc, wl);
+                cur.diff = D;
+                cur.idx = uni((int)cand[cb].idx); cur.ch = uni((int)(cand[cb].chj & 0x1ff)); cur.gid = uni((int)cand[cb].gid);
+                cur.valid = true;
+                wave_sync();
+                if (lane == 0) cand[cb].diff = -1.0;
+                fetch(cur);
             }
+            const double diff = cur.diff;
+            const int idx = cur.idx, ch = cur.ch, gid = cur.gid;
             const OrlgPhySvc *r = grec + idx;
             {
                 const OrlgPathRec *rec = tb.recs + gid;
-                const int row = tb.pair_row[tb.path_pair[gid]];
-                // the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): right
-                // when both serve the same node pair, otherwise its loop runs out and leaves k - 1
-                const int idp = (gid >= base_cur && gid < base_cur + K) ? gid - base_cur : K - 1;
-                const uint8_t *mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
-                // one trip: the candidate's level and the level of every channel
-                const int level_l = (int)mrow[ch];
-                int lev_w[W];
-#pragma unroll
-                for (int w = 0; w < W; ++w) lev_w[w] = (int)mrow[64 * w + lane];
-                const int level = uni(level_l);
+                const uint8_t *mrow = cur.mrow;
+                const int level = uni(cur.level_l);
                 u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
                 // only channels of the candidate's modulation level can take it over: words without one are not scored
                 {
                     u64 mine = 0ull;
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
-                        const u64 same = ballot(lev_w[w] == level);
+                        const u64 same = ballot(cur.lev_w[w] == level);
                         if (lane == w) mine = same;
                     }
                     acc &= mine;
                 }
-                int lv[W];
-                double mtr[W];
-                uint32_t cols[W];
-                phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
-                phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv);
-                int l0, c0;
-                double m0;
-                phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
+                int l0 = -1, c0 = -1;
+                double m0 = 0.0;
+                if (gnv && !rss) {
+                    // cut metric of the lane's channels from D (registers) and the path's node weights: an integer; the best
+                    // channel = greatest metric, then lowest channel number, as ONE key
+                    NvRec nr;
+                    {
+                        const uint4 bq = cur.nr1;
+                        nr.c = cur.nr0;
+                        nr.wsum = (int)(int16_t)(bq.x & 0xffffu); nr.cq = (int)(int16_t)(bq.x >> 16);
+                        nr.nchord = (int)(bq.y & 0xffu);
+                        nr.cl_lo = (bq.y >> 8) | (bq.z << 24); nr.cl_hi = (bq.z >> 8) & 0xffu;
+                        nr.cw_lo = (bq.z >> 16) | (bq.w << 16); nr.cw_hi = (bq.w >> 16) & 0xffu;
+                    }
+                    int key = -1;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const u64 x = readlane64(acc, w);
+                        const int cc = 64 * w + lane;
+                        const bool fr = ((x >> lane) & 1ull) && cc < p.C;
+                        int s = nv_dot(nr.c, dv[w]) - nr.cq;
+                        if (nr.nchord) s -= nv_chords(occ, nr, cc, W);
+                        const int kk = ((nr.wsum - 2 * s + 1024) << 9) | (511 - cc);   // |metric| <= sum of the weights < 1024
+                        if (fr && kk > key) key = kk;
+                    }
+                    key = wave_max_i32(key);
+                    if (key >= 0) { l0 = 0; c0 = 511 - (key & 511); m0 = (double)((key >> 9) - 1024); }
+                } else {
+                    int lv[W];
+                    double mtr[W];
+                    uint32_t cols[W];
+                    phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
+                    phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv);
+                    phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
+                }
                 if (l0 >= 0 && -1.0 * m0 < diff) {
                     // _move (:662-697): the service's channel list is read now -- the moved entry goes to its end
                     const int nch = uni((int)r->nch);
@@ -933,11 +1017,16 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
                     if (jm) {
                         const int j = ctz64(jm);
+                        mc_before(occ, mc, c0, lane);
+                        mc_before(occ, mc, ch, lane);
                         if (lane < rec->hops) {
                             u64 *rowp = occ + (int)rec->link[lane] * W;
                             rowp[c0 >> 6] &= ~(1ull << (c0 & 63));
                             rowp[ch >> 6] |= 1ull << (ch & 63);
                         }
+                        wave_sync();
+                        mc_after(occ, mc, c0, lane);
+                        mc_after(occ, mc, ch, lane);
                         if (gnv) {
                             const uint4 cv = p.nvrec[2 * gid];
                             if (lane < 2) nv_update(gnv, cv, lane == 0 ? c0 : ch, lane != 0);
@@ -948,11 +1037,11 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                                 if (cc == ch) { dv[w].x += cv.x; dv[w].y += cv.y; dv[w].z += cv.z; dv[w].w += cv.w; }
                             }
                         }
-                        const int nxt = __shfl_down(mych, 1);
-                        int nv = mych;
-                        if (lane >= j && lane + 1 < nch) nv = nxt;
-                        if (lane == nch - 1) nv = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
-                        if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv;
+                        const int nxtc = __shfl_down(mych, 1);
+                        int nv2 = mych;
+                        if (lane >= j && lane + 1 < nch) nv2 = nxtc;
+                        if (lane == nch - 1) nv2 = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
+                        if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv2;
                         if (lane == 0) grec[idx].seq = (uint32_t)next_seq;
                         next_seq += 1;
                         cmoves += 1;
@@ -973,7 +1062,9 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     wave_sync();
 }
 
-template <int W>
+// DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
+// without it run the other one, whose registers are not shared with code they never execute
+template <int W, bool DF>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     {
@@ -1031,7 +1122,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     nb.horizon = -__longlong_as_double((long long)ORLG_INF_BITS);  // the first look at the queue rebuilds the buffer
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
-    uint4 *gnv = p.use_nv ? p.nv + (size_t)env * p.cpad : nullptr;   // node-degree vectors of the cut metric
+    uint4 *gnv = (DF && p.use_nv) ? p.nv + (size_t)env * p.cpad : nullptr;   // node-degree vectors of the cut metric
 
     SEC(1);  // state load
     // ------------------------------------------------------------------ HBM -> LDS
@@ -1066,6 +1157,23 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     int *sel_cap = reinterpret_cast<int *>(scratch) + 16;      // [16] their capacity (modulation level)
     int *sel_used = reinterpret_cast<int *>(scratch) + 32;     // [16] the share this service uses
     double *scratch_d = reinterpret_cast<double *>(scratch + 64);  // [W*64] per-channel doubles
+
+    // per-step totals (number_cuts_total / rss_total_metric) kept incrementally over the launch when they are asked for
+    MetricCache mc;
+    mc.on = p.mode == ORLG_MODE_STEP && p.use_masks && p.cterm != nullptr &&
+            (p.out_mask & ((1 << ORLG_PHY_OUT_CUTS) | (1 << ORLG_PHY_OUT_RSS))) != 0;
+    mc.want_rss = (p.out_mask & (1 << ORLG_PHY_OUT_RSS)) != 0;
+    mc.total_runs = 0;
+    mc.cterm = p.cterm ? p.cterm + (size_t)env * p.cpad : nullptr;
+    mc.sqrt_tab = tb.sqrt_tab; mc.E = E; mc.W = W;
+    if (mc.on) {
+        double c0_unused, r0_unused;
+        phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, true, mc.want_rss, true, c0_unused, r0_unused, mc.total_runs);
+        if (mc.want_rss) {
+            for (int ch = lane; ch < C; ch += 64) mc.cterm[ch] = scratch_d[ch];
+            wave_sync();
+        }
+    }
 
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
@@ -1294,12 +1402,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
                 if (ballot(bad) == 0ull) {
                     // _provision_path (:544-623): one lane per hop clears the channels on its link
+                    for (int ci = 0; ci < nsel; ++ci) mc_before(occ, mc, sel_ch[ci], lane);
                     if (lane < hops) {
                         u64 *rowp = occ + (int)rec->link[lane] * W;
                         for (int ci = 0; ci < nsel; ++ci) {
                             const int ch = sel_ch[ci];
                             rowp[ch >> 6] &= ~(1ull << (ch & 63));
                         }
+                    }
+                    if (mc.on) {
+                        wave_sync();
+                        for (int ci = 0; ci < nsel; ++ci) mc_after(occ, mc, sel_ch[ci], lane);
                     }
                     if (gnv) {   // the nodes of the path lose free links on these channels
                         const uint4 cv = p.nvrec[2 * gid];
@@ -1377,7 +1490,22 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 const size_t o = (size_t)t * p.B + env;
                 double cuts = 0.0, rss = 0.0;
                 const bool want_c = om & (1 << ORLG_PHY_OUT_CUTS), want_r = om & (1 << ORLG_PHY_OUT_RSS);
-                if (want_c || want_r) phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, want_c, want_r, p.use_masks != 0, cuts, rss);
+                if (mc.on) {
+                    cuts = (double)mc.total_runs / (double)C;
+                    if (want_r) {
+                        // the terms other lanes rewrote are complete; through LDS, then the reference's channel-order sum
+                        nv_fence();
+                        for (int ch = lane; ch < C; ch += 64) scratch_d[ch] = mc.cterm[ch];
+                        wave_sync();
+                        double r = 0.0;
+                        for (int ch = 0; ch < C; ++ch) r += scratch_d[ch];
+                        rss = r / (double)C;
+                        wave_sync();
+                    }
+                } else if (want_c || want_r) {
+                    int tr_unused;
+                    phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, want_c, want_r, p.use_masks != 0, cuts, rss, tr_unused);
+                }
                 if (om & (1 << ORLG_PHY_OUT_CHANNELS)) {
                     int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CHANNELS]) + o * ORLG_PHY_MAX_CH;
                     if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_ch[lane] : (int16_t)-1;
@@ -1503,10 +1631,21 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                     cs_store(gcs, gcs_n, key, l, lane);
                 }
+                if (mc.on) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_before(occ, mc, 64 * w + ctz64(m), lane);
+                }
                 if (lane < rec->hops) {
                     u64 *rowp = occ + (int)rec->link[lane] * W;
 #pragma unroll
                     for (int w = 0; w < W; ++w) rowp[w] |= freemask[w];
+                }
+                if (mc.on) {
+                    wave_sync();
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_after(occ, mc, 64 * w + ctz64(m), lane);
                 }
                 if (gnv) {   // the returned channels: lane = channel of word w, the nodes of the path gain free links
                     const uint4 cv = p.nvrec[2 * (int)sv.gid];
@@ -1534,13 +1673,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             }
         }
 
-        if (p.mode == ORLG_MODE_STEP && p.defrag_period > 0) {
+        if (DF && p.mode == ORLG_MODE_STEP && p.defrag_period > 0) {
         SEC(11);  // defragmentation
             // periodic defragmentation (phy_rmsa_env.py:355-417): services_processed % defrag_period == 0
             wave_sync();
             const long long processed = ws->c[0];
             if (processed % p.defrag_period == 0)
-                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv SEC_ARGS);
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv, mc SEC_ARGS);
         }
 
         if (p.mode == ORLG_MODE_STEP) {

@@ -124,7 +124,8 @@ class BatchedPhyRMSAEnv:
         # keeps the adjacency-list evaluation (identical results: tests/test_gpu_phy.py runs both)
         import os
         nv = t.cut_node_tables() if os.environ.get("ORLG_PHY_NODEVEC", "1") != "0" else None
-        self.node_vectors = nv is not None
+        # (the library uses them when the periodic defragmentation is on: include/orlg.h; ORLG_PHY_NODEVEC=2 always)
+        self.node_vectors = nv is not None and (bool(defrag_period) or os.environ.get("ORLG_PHY_NODEVEC") == "2")
         if nv is not None:
             cc.path_node_weights, cc.node_degree = keep(nv[0], np.uint8), keep(nv[1], np.uint8)
         seeds_ptr = None

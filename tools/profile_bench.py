@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--extra", default="", help="extra bench.py arguments, e.g. '--step-kernel wave'")
     ap.add_argument("--suffix", default="", help="appended to the output names and the pmc.json key")
     args = ap.parse_args()
-    kpat, key, B, chunk = WORK[args.name]
+    kpat, key, B, chunk = WORK[args.name]  # (kernel pattern: substring of the kernel name)
     key += args.suffix
     os.makedirs(OUT, exist_ok=True)
     scratch = os.path.join(ROOT, "gpurun_out", f"prof_{args.tag}_{args.name}{args.suffix}")
