@@ -74,9 +74,7 @@ typedef struct orlg_rmsa_config {
 
 /* Two step kernels share one state format.  WAVE: one wavefront per environment (every policy).  GROUP: four environments
  * per wavefront, 16 lanes each (every policy but load balancing, which runs on WAVE).  AUTO picks GROUP for a batch larger
- * than the WAVE kernel's resident wavefronts (4096 on MI355X) when the launch has more than 16 steps or the shape leaves GROUP at
- * least 10 wavefronts per CU, WAVE otherwise.  Results are
- * identical bit for bit. */
+ * than the WAVE kernel's resident wavefronts (4096 on MI355X), WAVE otherwise.  Results are identical bit for bit. */
 enum { ORLG_KERNEL_AUTO = 0, ORLG_KERNEL_WAVE = 1, ORLG_KERNEL_GROUP = 2 };
 
 enum {
@@ -218,6 +216,7 @@ int orlg_reduce_counters(orlg_env *env, int64_t *out /* [16], host or device */)
  * leaves the rest in channel_state[src, dst, k-path] (phy_rmsa_env.py:600-602), where use_existing_channels (:1650-1673)
  * finds it for later requests of the same (source, destination, k-path): action path = 20 + k-path (:280-288).
  */
+struct orlg_gn_gate;
 typedef struct orlg_phy_config {
     int32_t num_channels;     /* 2*number_spectrum_channels + number_spectrum_channels_s_band (optical_network_env.py:78-84) */
     int32_t episode_length;
@@ -251,7 +250,29 @@ typedef struct orlg_phy_config {
      * costs a step one read-after-write round trip, so the library uses it when the periodic defragmentation is on (hundreds
      * of evaluations per cycle) and the LDS adjacency lists otherwise. */
     const uint8_t *path_node_weights, *node_degree;
+    const struct orlg_gn_gate *gn_gate; /* GN-model admission check of the chosen channels; NULL = off (the reference) */
 } orlg_phy_config;
+
+/* GN-model admission check inside the QoT-aware step (north_star: "GN-model OSNR admission check").  The reference gates by
+ * table only (phy_rmsa_env.py:596, 1279, 1341, 1398): this mode has NO reference behaviour -- PARITY UNPINNED; it is pinned
+ * to the oracle's restatement (oracle/orlg_oracle_phy.c gn_gsnr_db), which feeds the restatement of
+ * examples/calculate_osnr.py:9-56 with the LIVE occupancy.  After the policy (or the caller) has chosen (path, channels) on
+ * the physical layer and they are free, every chosen channel is checked: GSNR of a channel of channel_bandwidth_hz at
+ * channel_center_frequency_hz[channel] over the path's links -- link l = link_num_spans[l] equal spans of
+ * link_span_length_km[l] (examples/create_topology_gn.py:122-125), every lit channel of the link an interferer of the same
+ * bandwidth at its own centre frequency whose modulation is the QoT table's level for that channel on the candidate path.
+ * level = number of thresholds_db met; if it is below the capacity level the table promised for the channel, the service
+ * is blocked (not accepted).  Services served on the virtual layer light nothing new and are not checked. */
+typedef struct orlg_gn_gate {
+    double launch_power_w, channel_bandwidth_hz;
+    double attenuation_normalized;  /* 1/m */
+    double noise_figure;            /* linear */
+    const double *channel_center_frequency_hz; /* [num_channels] */
+    const int32_t *link_num_spans;              /* [num_links] */
+    const double *link_span_length_km;          /* [num_links] */
+    const double *thresholds_db;                /* [num_thresholds] ascending */
+    int32_t num_thresholds, pad;
+} orlg_gn_gate;
 
 enum {
     ORLG_PHY_POLICY_EXTERNAL = -1, /* caller supplies (path, channels) per env */
@@ -277,6 +298,7 @@ typedef struct orlg_phy_step_io { /* optional per-step outputs, [n_steps][B] eac
     int16_t *channels_used;     /* [n_steps][B][ORLG_PHY_MAX_CHANNELS] share of each channel the service uses, 100 Gb/s units */
     int32_t *defrag_counters;   /* [n_steps][B][3] counted_moves, counted_moves_groom, counted_defrag_cycles as the step's info
                                  * dict sees them (phy_rmsa_env.py:340-342: before the step's own defragmentation) */
+    double *gn_gsnr_db;         /* GN gate: GSNR [dB] of the last channel the step checked, NaN when it checked none */
 } orlg_phy_step_io;
 
 typedef struct orlg_phy_episode_stats { /* per-episode sums behind the info dict (phy_rmsa_env.py:339-347) */

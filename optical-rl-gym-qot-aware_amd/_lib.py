@@ -61,20 +61,27 @@ class PhyConfig(C.Structure):
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight",
-                                          "path_node_weights", "node_degree")]
+                                          "path_node_weights", "node_degree", "gn_gate")]
+
+
+class GnGate(C.Structure):
+    _fields_ = [("launch_power_w", C.c_double), ("channel_bandwidth_hz", C.c_double), ("attenuation_normalized", C.c_double),
+                ("noise_figure", C.c_double), ("channel_center_frequency_hz", C.c_void_p), ("link_num_spans", C.c_void_p),
+                ("link_span_length_km", C.c_void_p), ("thresholds_db", C.c_void_p), ("num_thresholds", C.c_int32),
+                ("pad", C.c_int32)]
 
 
 class PhyStepIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("act_path", "n_channels", "channels", "accepted", "done", "request",
                                          "arrival", "holding", "number_cuts_total", "rss_total_metric",
-                                         "channels_used", "defrag_counters")]
+                                         "channels_used", "defrag_counters", "gn_gsnr_db")]
 
 
 PHY_MAX_CHANNELS = 14
 PHY_STEP_IO_DTYPES = {"act_path": "int32", "n_channels": "int32", "channels": "int16", "accepted": "uint8",
                       "done": "uint8", "request": "int32", "arrival": "float64", "holding": "float64",
                       "number_cuts_total": "float64", "rss_total_metric": "float64", "channels_used": "int16",
-                      "defrag_counters": "int32"}
+                      "defrag_counters": "int32", "gn_gsnr_db": "float64"}
 PHY_POLICIES = {"external": -1, "bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff": 5, "faff_rss": 6}
 
 _lib = None

@@ -307,12 +307,11 @@ static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
     if (e->group_mode == ORLG_KERNEL_WAVE || p.mode != ORLG_MODE_STEP) return false;
     if (p.policy == ORLG_POLICY_LLP) return false;  // the only policy the four-environments-per-wave kernel does not carry
     if (e->group_mode == ORLG_KERNEL_GROUP) return true;
-    // AUTO: this kernel's advantage is throughput once the batch exceeds what the wave-per-environment kernel keeps resident
-    // (595 vs 435 M env-steps/s at B = 4096, 507 vs 781 M at B = 8192, 601 vs 998 M at B = 65 536).  A launch of a few steps
-    // is dominated by moving the state between HBM and LDS: there it wins when its LDS footprint leaves it at least 10 waves
-    // per CU (B = 32 768, one step per launch: 287 vs 250 M with 11 waves; DeepRMSA's 192-slot queue leaves 9: 0.170 vs 0.166 ms).
-    if (p.B <= e->resident_blocks * e->waves_per_block) return false;
-    return p.n_steps > 16 || e->group_wpb >= 10;
+    // AUTO: this kernel once the batch exceeds what the wave-per-environment kernel keeps resident (4096 environments on
+    // MI355X) -- long launches (B = 65 536: 1140 vs 630 M env-steps/s) and launches of one step alike (B = 32 768, DeepRMSA
+    // shape: 0.145 vs 0.161 ms per step + observation); at or below it the wave-per-environment kernel has the shorter step
+    // (B = 4096: 630 vs 440 M).
+    return p.B > e->resident_blocks * e->waves_per_block;
 }
 
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {

@@ -264,8 +264,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
 
     // ------------------------------------------------------------------ HBM -> LDS
     row_copy8(occ, p.occ + (size_t)env * NW, NW, gl);
-    row_copy16(qtime, p.qtime + (size_t)env * Q, Q * 8, gl);
-    row_copy16(qdesc, p.qdesc + (size_t)env * Q, Q * 4, gl);
     if (FULL) row_copy16(lst, p.lstat + (size_t)env * 4 * E, 4 * E * 8, gl);
     // the bit-rate histograms are only ever incremented (and zeroed at an episode's end): they stay in HBM and take L2 atomics
     // without return -- 336 bytes of LDS per environment decide how many waves a CU keeps resident.  Every access
@@ -289,7 +287,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     // release queue: a time-sorted ring in LDS (OrlgParams::qtime) -- q_n entries from slot q_head on; the row keeps the time of
     // its head in a register, so that a step without a due release touches no queue memory
     int q_head = gs->q_head, q_n = n_running < Q ? n_running : Q;   // (n_running also counts services an overflow lost)
-    double next_rel = qtime[q_head];   // +inf when the queue is empty
+    // only the live part of the ring moves between HBM and LDS (a launch of one step would otherwise spend most of its
+    // traffic on empty slots); LDS slots outside it are never read
+    const int q_head0 = q_head;
+    {
+        const double *gqt = p.qtime + (size_t)env * Q;
+        const uint32_t *gqd = p.qdesc + (size_t)env * Q;
+        for (int j = gl; j < q_n; j += ORLG_GL) {
+            int pos = q_head + j;
+            pos -= pos >= Q ? Q : 0;
+            qtime[pos] = gqt[pos]; qdesc[pos] = gqd[pos];
+        }
+    }
+    wave_sync();
+    double next_rel = q_n > 0 ? qtime[q_head] : INF;
     const int cidx = gl & 7;
     int req_base = tb.pair_base[req_src * N + req_dst];  // first path record of the pending request's node pair
 
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                     released = true;
                 }
                 group_apply_window<W>(lane, occ, rec2->link, rel_now ? hops2 : 0, s0, n2, true);   // (ends with a wave_sync)
-                if (rel_now) next_rel = qtime[q_head];   // the next entry, +inf when none is left
+                if (rel_now) next_rel = q_n > 0 ? qtime[q_head] : INF;   // the next entry
                 SEC(11);  // statistics at release
                 if (NET)
                     group_link_stats<W, FULL, false>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
@@ -598,8 +609,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     wave_sync();
     if (act) {
         row_copy8(p.occ + (size_t)env * NW, occ, NW, gl);
-        row_copy16(p.qtime + (size_t)env * Q, qtime, Q * 8, gl);
-        row_copy16(p.qdesc + (size_t)env * Q, qdesc, Q * 4, gl);
+        {
+            // the ring from where its head was at the start (slots popped since then hold (+inf, 0)) to its last entry
+            double *gqt = p.qtime + (size_t)env * Q;
+            uint32_t *gqd = p.qdesc + (size_t)env * Q;
+            int span = q_head - q_head0;
+            span += span < 0 ? Q : 0;
+            span += q_n;
+            span = span > Q ? Q : span;
+            for (int j = gl; j < span; j += ORLG_GL) {
+                int pos = q_head0 + j;
+                pos -= pos >= Q ? Q : 0;
+                gqt[pos] = qtime[pos]; gqd[pos] = qdesc[pos];
+            }
+        }
         if (FULL) row_copy16(p.lstat + (size_t)env * 4 * E, lst, 4 * E * 8, gl);
         if (NET) row_copy16(p.lint + (size_t)env * p.lint_stride, lint, p.lint_stride * 4, gl);
         OrlgEnvScalars *go = p.scal + env;

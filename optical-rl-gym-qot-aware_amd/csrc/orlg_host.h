@@ -58,6 +58,6 @@ ORLG_FOR_EACH_W(ORLG_DECL_W)
 struct OrlgPhyParams;
 typedef void (*orlg_phy_kernel_t)(const OrlgPhyParams);
 #define ORLG_FOR_EACH_PHY_W(X) X(1) X(2) X(3) X(4) X(5)
-#define ORLG_DECL_PHY_W(n) orlg_phy_kernel_t orlg_phy_kernel_W##n(int defragmentation) __attribute__((weak));
+#define ORLG_DECL_PHY_W(n) orlg_phy_kernel_t orlg_phy_kernel_W##n(int variant) __attribute__((weak));
 ORLG_FOR_EACH_PHY_W(ORLG_DECL_PHY_W)
 #undef ORLG_DECL_PHY_W

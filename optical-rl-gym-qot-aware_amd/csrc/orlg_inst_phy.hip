@@ -9,6 +9,9 @@
 #define ORLG_CAT2(a, b) a##b
 #define ORLG_CAT(a, b) ORLG_CAT2(a, b)
 
-orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)(int defragmentation) {
-    return defragmentation ? orlg_phy_kernel<ORLG_INST_W, true> : orlg_phy_kernel<ORLG_INST_W, false>;
+// variant 0: the step kernel proper; 1: + periodic defragmentation (and the node-degree vectors of its cut metric); 2: + the
+// GN-model admission check
+orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)(int variant) {
+    return variant == 2 ? orlg_phy_kernel<ORLG_INST_W, true, true>
+                        : variant == 1 ? orlg_phy_kernel<ORLG_INST_W, true, false> : orlg_phy_kernel<ORLG_INST_W, false, false>;
 }

@@ -30,9 +30,9 @@ static int phy_sync_check(orlg_phy_env *e) {
 }
 
 typedef orlg_phy_kernel_t phy_kernel_t;
-static phy_kernel_t pick_phy(int W, int defragmentation) {
+static phy_kernel_t pick_phy(int W, int variant) {
     switch (W) {
-#define X(n) case n: return orlg_phy_kernel_W##n ? orlg_phy_kernel_W##n(defragmentation) : nullptr;
+#define X(n) case n: return orlg_phy_kernel_W##n ? orlg_phy_kernel_W##n(variant) : nullptr;
         ORLG_FOR_EACH_PHY_W(X)
 #undef X
         default: return nullptr;
@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
 }
 
 static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
-    const int df = (p.defrag_period > 0 || p.use_nv) ? 1 : 0;   // (use_nv without the defragmentation: ORLG_PHY_NODEVEC=2, tests)
+    // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation (use_nv without it:
+    // ORLG_PHY_NODEVEC=2, tests), 2 + GN-model admission check
+    const int df = p.gn_on ? 2 : (p.defrag_period > 0 || p.use_nv) ? 1 : 0;
     phy_kernel_t k = pick_phy(e->W, df);
     if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -132,7 +134,7 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d,%s> grid=%d block=%d lds=%zu", e->W,
-             df ? "true" : "false", nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
+             df == 2 ? "true,true" : df == 1 ? "true,false" : "false,false", nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 
@@ -406,6 +408,30 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.nvrec = d_rec;
         memcpy(&p.deg, c->node_degree, 16);
     }
+    if (c->gn_gate) {
+        const orlg_gn_gate *g = c->gn_gate;
+        if (!g->channel_center_frequency_hz || !g->link_num_spans || !g->link_span_length_km || !g->thresholds_db || g->num_thresholds < 1 ||
+            !(g->launch_power_w > 0) || !(g->channel_bandwidth_hz > 0) || !(g->attenuation_normalized > 0) || !(g->noise_figure > 0)) {
+            orlg_phy_destroy(e);
+            return fail(ORLG_ERR_INVALID, "gn_gate: missing array or non-positive physical parameter");
+        }
+        for (int l = 0; l < E; l++)
+            if (g->link_num_spans[l] < 1 || !(g->link_span_length_km[l] > 0)) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "gn_gate: link %d has no spans", l); }
+        double *d_cf = nullptr, *d_sl = nullptr, *d_thr = nullptr;
+        int32_t *d_ns = nullptr;
+        TRY(alloc(reinterpret_cast<void **>(&d_cf), (size_t)C * 8));
+        TRY(alloc(reinterpret_cast<void **>(&d_sl), (size_t)E * 8));
+        TRY(alloc(reinterpret_cast<void **>(&d_thr), (size_t)g->num_thresholds * 8));
+        TRY(alloc(reinterpret_cast<void **>(&d_ns), (size_t)E * 4));
+        hipError_t er = hipMemcpy(d_cf, g->channel_center_frequency_hz, (size_t)C * 8, hipMemcpyHostToDevice);
+        if (er == hipSuccess) er = hipMemcpy(d_sl, g->link_span_length_km, (size_t)E * 8, hipMemcpyHostToDevice);
+        if (er == hipSuccess) er = hipMemcpy(d_thr, g->thresholds_db, (size_t)g->num_thresholds * 8, hipMemcpyHostToDevice);
+        if (er == hipSuccess) er = hipMemcpy(d_ns, g->link_num_spans, (size_t)E * 4, hipMemcpyHostToDevice);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "upload of the GN gate tables: %s", hipGetErrorString(er)); }
+        p.gn_on = 1; p.gn_nthr = g->num_thresholds;
+        p.gn_pw = g->launch_power_w; p.gn_bw = g->channel_bandwidth_hz; p.gn_att = g->attenuation_normalized; p.gn_nf = g->noise_figure;
+        p.gn_cf = d_cf; p.gn_nspans = d_ns; p.gn_spanlen = d_sl; p.gn_thr = d_thr;
+    }
     if (p.use_masks) TRY(alloc(reinterpret_cast<void **>(&p.cterm), (size_t)batch * p.cpad * sizeof(double)));   // (scratch, see OrlgPhyParams)
     if (p.defrag_period > 0) {
         // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
@@ -493,7 +519,7 @@ int orlg_phy_step(orlg_phy_env *e, int32_t policy, int32_t n_steps, const int32_
         {io ? io->accepted : nullptr, 1},  {io ? io->done : nullptr, 1},       {io ? io->request : nullptr, 16},
         {io ? io->arrival : nullptr, 8},   {io ? io->holding : nullptr, 8},    {io ? io->number_cuts_total : nullptr, 8},
         {io ? io->rss_total_metric : nullptr, 8}, {io ? io->channels_used : nullptr, 2 * ORLG_PHY_MAX_CH},
-        {io ? io->defrag_counters : nullptr, 12}};
+        {io ? io->defrag_counters : nullptr, 12}, {io ? io->gn_gsnr_db : nullptr, 8}};
     bool staged[ORLG_PHY_NUM_OUTS] = {false};
     p.out_mask = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) {

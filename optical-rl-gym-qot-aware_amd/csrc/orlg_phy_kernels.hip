@@ -60,7 +60,7 @@ static_assert(sizeof(OrlgPhyScalars) == 224, "OrlgPhyScalars layout");
 // policies: ORLG_PHY_POLICY_* of include/orlg.h
 enum { ORLG_PHY_OUT_PATH = 0, ORLG_PHY_OUT_NCH, ORLG_PHY_OUT_CHANNELS, ORLG_PHY_OUT_ACCEPTED, ORLG_PHY_OUT_DONE,
        ORLG_PHY_OUT_REQUEST, ORLG_PHY_OUT_ARRIVAL, ORLG_PHY_OUT_HOLDING, ORLG_PHY_OUT_CUTS, ORLG_PHY_OUT_RSS,
-       ORLG_PHY_OUT_CH_USED, ORLG_PHY_OUT_DEFRAG, ORLG_PHY_NUM_OUTS };
+       ORLG_PHY_OUT_CH_USED, ORLG_PHY_OUT_DEFRAG, ORLG_PHY_OUT_GN, ORLG_PHY_NUM_OUTS };
 
 struct OrlgPhyParams {
     int32_t B, N, E, C, K, NBR, Q, NW;
@@ -89,6 +89,13 @@ struct OrlgPhyParams {
     const uint4 *nvrec;     // [num_paths][2] node weights c (16 bytes) | wsum, cq (int16), chords
     uint4 deg;              // links per node
     int32_t use_nv, pad_nv;
+    // GN-model admission check of the chosen channels (include/orlg.h orlg_gn_gate), gn_on = 0: off
+    int32_t gn_on, gn_nthr;
+    double gn_pw, gn_bw, gn_att, gn_nf;
+    const double *gn_cf;        // [C] centre frequencies
+    const int32_t *gn_nspans;   // [E]
+    const double *gn_spanlen;   // [E] km
+    const double *gn_thr;       // [gn_nthr] dB, ascending
     double *cterm;          // [B][cpad] scratch: per-channel term of calculate_total_r_spatial while a launch keeps the per-step
                             // totals incrementally (not part of the state: rebuilt at the start of every launch that needs it)
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
@@ -1062,9 +1069,65 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     wave_sync();
 }
 
+// GN-model GSNR [dB] of channel `ch` on the path `rec` against the live occupancy (include/orlg.h orlg_gn_gate): the
+// arithmetic of examples/calculate_osnr.py:9-56 for a service that is not yet in the links' lists.  Wave-cooperative, result
+// wave-uniform.  Lanes = channels: the two asinh terms and the modulation term of an interferer depend on the fibre only
+// through its attenuation, uniform here, so they are evaluated once per channel (A, B) and summed per link over the channels
+// the link has lit (the reference's per-interferer sum, re-associated: ~1e-15 relative); the spans of a link are equal, their
+// contribution is added span by span like the reference does.
+template <int W>
+DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *rec, const uint8_t *mrow, int ch, int lane) {
+    const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = 3.141592653589793;
+    const double bw = p.gn_bw, pw = p.gn_pw, att = p.gn_att, nf = p.gn_nf;
+    const double fc = p.gn_cf[ch];
+    const double l_eff_a = 1 / (2 * att);
+    double A[W], B[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int c = 64 * w + lane;
+        const bool valid = c < p.C && c != ch;
+        A[w] = 0.0; B[w] = 0.0;
+        if (valid) {
+            const double sf = p.gn_cf[c];
+            int se = (int)mrow[c];
+            se = se < 1 ? 1 : (se > 6 ? 6 : se);
+            const double pm = se <= 2 ? 1.0 : se == 3 ? 2.0 / 3 : se == 4 ? 17.0 / 25 : se == 5 ? 69.0 / 100 : 13.0 / 21;
+            A[w] = asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc + (bw / 2))) -
+                   asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc - (bw / 2)));
+            B[w] = pm * (bw / fabs(sf - fc)) * 5 / 3;
+        }
+    }
+    const double base = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4 * att));
+    const double r = pw / bw;
+    double acc = 0.0;
+    const int hops = rec->hops;
+    for (int h = 0; h < hops; ++h) {
+        const int link = (int)rec->link[h];
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const bool lit = !((occ[__mul24(link, W) + w] >> lane) & 1ull);   // (A, B are 0 on channels that do not exist)
+            sa += lit ? A[w] : 0.0;
+            sb += lit ? B[w] : 0.0;
+        }
+        const double SA = wave_add_f64(sa), SB = wave_add_f64(sb);
+        const double len = p.gn_spanlen[link];
+        const int ns = p.gn_nspans[link];
+        const double l_eff = (1 - exp(-2 * att * len * 1e3)) / (2 * att);
+        const double ratio = l_eff / (len * 1e3);
+        const double sum_phi = base + (SA - (SB * ratio));
+        const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sum_phi * bw;
+        const double power_ase = bw * h_plank * fc * (exp(2 * att * len * 1e3) - 1) * nf;
+        const double g = 1 / (pw / (power_ase + power_nli_span));
+        for (int s = 0; s < ns; ++s) acc += g;
+    }
+    return 10 * log10(1 / acc);
+}
+
 // DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
 // without it run the other one, whose registers are not shared with code they never execute
-template <int W, bool DF>
+// GN: ... and the one that also carries the GN-model admission check (orlg_gn_gate)
+template <int W, bool DF, bool GN>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     {
@@ -1337,6 +1400,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             SEC(5);  // provision
             // ========================================================== PhyRMSAEnv.step (phy_rmsa_env.py:272-351)
             bool accepted = false;
+            double gn_last = __longlong_as_double(0x7ff8000000000000ll);   // NaN: no GN check in this step
             const bool dirbit = req_src > req_dst;
             if (a_path > 10 && a_path - 20 < K && nsel > 0) {
                 // ---- virtual layer: _service_acceptance(True), _provision_virtual_path (:280-288, 625-659)
@@ -1400,7 +1464,19 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         bad = bad || !((occ[(int)rec->link[h] * W + (ch >> 6)] >> (ch & 63)) & 1ull);
                     }
                 }
-                if (ballot(bad) == 0ull) {
+                bool pass = ballot(bad) == 0ull;
+                if (GN && p.gn_on && pass) {
+                    // GN gate (not in the reference): every chosen channel must reach the level the table promised
+                    const uint8_t *mrow_g = p.mod_t + (size_t)(row * K + a_path) * p.cpad;
+                    for (int ci = 0; ci < nsel && pass; ++ci) {
+                        const double gdb = gn_gsnr<W>(p, occ, rec, mrow_g, sel_ch[ci], lane);
+                        int level = 0;
+                        for (int q = 0; q < p.gn_nthr; ++q) level += gdb >= p.gn_thr[q] ? 1 : 0;
+                        gn_last = gdb;
+                        if (level < sel_cap[ci]) pass = false;
+                    }
+                }
+                if (pass) {
                     // _provision_path (:544-623): one lane per hop clears the channels on its link
                     for (int ci = 0; ci < nsel; ++ci) mc_before(occ, mc, sel_ch[ci], lane);
                     if (lane < hops) {
@@ -1526,6 +1602,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         int32_t *od = reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_DEFRAG]) + o * 3;
                         od[0] = ws->counted_moves; od[1] = ws->counted_moves_groom; od[2] = ws->counted_defrag_cycles;
                     }
+                    if (om & (1 << ORLG_PHY_OUT_GN)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_GN])[o] = gn_last;
                     if (want_c) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_CUTS])[o] = cuts;
                     if (want_r) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
                 }

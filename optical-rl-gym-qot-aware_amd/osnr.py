@@ -50,3 +50,32 @@ def modulation_level_from_gsnr(gsnr_db, thresholds=None):
     """Number of thresholds met = table modulation level (0 = unusable)."""
     t = np.array([0.5 * (a + b) for a, b in (thresholds or TABLE_THRESHOLDS_DB)])
     return (np.asarray(gsnr_db)[..., None] >= t).sum(axis=-1).astype(np.uint8)
+
+
+def gn_gate_parameters(topology, num_channels=268, *, launch_power_dbm=0.0, channel_spacing_hz=50e9,
+                       first_center_frequency_hz=184.5e12, max_span_length_km=80.0, attenuation_db_km=0.2,
+                       noise_figure_db=4.5, thresholds_db=None):
+    """Parameters of the GN-model admission check of ``BatchedPhyRMSAEnv(..., gn_gate=...)`` (``include/orlg.h``
+    ``orlg_gn_gate``): a plain dict of numbers / arrays, physical defaults of ``examples/create_topology_gn.py``.
+
+    * spans: ``int(length // 80) + 1`` equal spans per link (``create_topology_gn.py:122-125``), 0.2 dB/km, NF 4.5 dB;
+      ``attenuation_normalized = att_dB_km / (2 * 10 * log10(e) * 1e3)`` [1/m] and ``noise_figure = 10 ** (NF_dB / 10)`` are
+      the conventions stated for the stand-alone routine (SURVEY 8c: the reference leaves them undefined);
+    * channels: a uniform grid ``f0 + index * spacing``, every channel ``spacing`` wide (L, C, S bands = 268 channels);
+    * thresholds: the GSNR levels the shipped QoT tables were built with (midpoints of :data:`TABLE_THRESHOLDS_DB`).
+    """
+    from .topology import FrozenTopology
+    t = FrozenTopology.from_graph(topology)
+    lengths = np.array([float(e[4]) for e in t.edges], np.float64)[np.argsort([int(e[2]) for e in t.edges])]
+    nspans = (lengths // max_span_length_km).astype(np.int32) + 1
+    thr = thresholds_db if thresholds_db is not None else [0.5 * (a + b) for a, b in TABLE_THRESHOLDS_DB]
+    return {
+        "launch_power_w": 1e-3 * 10 ** (launch_power_dbm / 10.0),
+        "channel_bandwidth_hz": float(channel_spacing_hz),
+        "attenuation_normalized": attenuation_db_km / (2 * 10 * np.log10(np.e) * 1e3),
+        "noise_figure": 10 ** (noise_figure_db / 10.0),
+        "channel_center_frequency_hz": first_center_frequency_hz + channel_spacing_hz * np.arange(num_channels, dtype=np.float64),
+        "link_num_spans": nspans,
+        "link_span_length_km": lengths / nspans,
+        "thresholds_db": np.asarray(sorted(thr), np.float64),
+    }

@@ -58,7 +58,7 @@ class BatchedPhyRMSAEnv:
                  number_spectrum_channels_s_band: int = 108, l_band: bool = True, s_band: bool = True,
                  defrag_period=None, number_moves=None, metric: str = "cut", grooming: bool = False,
                  queue_capacity: int = 0, channel_state_capacity: int = 0, defrag_capacity: int = 0, device: int = 0,
-                 **_ignored):
+                 gn_gate=None, **_ignored):
         if defrag_period and number_moves is None:
             raise ValueError("defrag_period needs number_moves (the reference compares against it, phy_rmsa_env.py:358)")
         self.L = _lib.load()
@@ -128,6 +128,23 @@ class BatchedPhyRMSAEnv:
         self.node_vectors = nv is not None and (bool(defrag_period) or os.environ.get("ORLG_PHY_NODEVEC") == "2")
         if nv is not None:
             cc.path_node_weights, cc.node_degree = keep(nv[0], np.uint8), keep(nv[1], np.uint8)
+        # GN-model admission check of the chosen channels (osnr.gn_gate_parameters; not in the reference: include/orlg.h)
+        self.gn_gate = gn_gate
+        if gn_gate is not None:
+            gg = _lib.GnGate()
+            gg.launch_power_w = float(gn_gate["launch_power_w"])
+            gg.channel_bandwidth_hz = float(gn_gate["channel_bandwidth_hz"])
+            gg.attenuation_normalized = float(gn_gate["attenuation_normalized"])
+            gg.noise_figure = float(gn_gate["noise_figure"])
+            cf = np.ascontiguousarray(gn_gate["channel_center_frequency_hz"], np.float64)
+            ns, sl = np.ascontiguousarray(gn_gate["link_num_spans"], np.int32), np.ascontiguousarray(gn_gate["link_span_length_km"], np.float64)
+            if cf.shape != (self.num_channels,) or ns.shape != (t.num_links,) or sl.shape != (t.num_links,):
+                raise ValueError("gn_gate: channel_center_frequency_hz [num_channels], link_num_spans / link_span_length_km [num_links]")
+            gg.channel_center_frequency_hz, gg.link_num_spans, gg.link_span_length_km = keep(cf, np.float64), keep(ns, np.int32), keep(sl, np.float64)
+            thr = np.ascontiguousarray(gn_gate["thresholds_db"], np.float64)
+            gg.thresholds_db, gg.num_thresholds = keep(thr, np.float64), len(thr)
+            self._keep.append(gg)
+            cc.gn_gate = C.cast(C.pointer(gg), C.c_void_p)
         seeds_ptr = None
         if seeds is not None:
             seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

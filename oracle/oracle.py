@@ -285,7 +285,11 @@ class PhyConfig(C.Structure):
                 ("number_moves", C.c_int32), ("defrag_metric", C.c_int32),
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
-                                          "modulation_level", "gsnr", "link_ends", "path_node_off", "path_nodes")]
+                                          "modulation_level", "gsnr", "link_ends", "path_node_off", "path_nodes")] + \
+               [("gn_on", C.c_int32), ("gn_num_thresholds", C.c_int32), ("gn_launch_power_w", C.c_double),
+                ("gn_channel_bandwidth_hz", C.c_double), ("gn_attenuation", C.c_double), ("gn_noise_figure", C.c_double),
+                ("gn_center_frequency_hz", C.c_void_p), ("gn_link_num_spans", C.c_void_p),
+                ("gn_link_span_length_km", C.c_void_p), ("gn_thresholds_db", C.c_void_p)]
 
 
 class PhyAction(C.Structure):
@@ -299,7 +303,8 @@ class PhyResult(C.Structure):
                                           "average_path_index", "service_blocking_rate", "episode_service_blocking_rate",
                                           "bit_rate_blocking_rate", "episode_bit_rate_blocking_rate")] + \
                [(n, C.c_int64) for n in ("total_modulation_level", "channels_accepted", "path_index", "physical_paths")] + \
-               [("num_moves", C.c_double), ("num_moves_groom", C.c_int64), ("num_defrag_cycle", C.c_int64)]
+               [("num_moves", C.c_double), ("num_moves_groom", C.c_int64), ("num_defrag_cycle", C.c_int64),
+                ("gn_gsnr_db", C.c_double)]
 
 
 PHY_TRACE_FIELDS = [
@@ -315,6 +320,7 @@ PHY_TRACE_FIELDS = [
     ("episode_service_blocking_rate", np.float64, 1), ("bit_rate_blocking_rate", np.float64, 1),
     ("current_time", np.float64, 1),
     ("num_moves", np.float64, 1), ("num_moves_groom", np.int64, 1), ("num_defrag_cycle", np.int64, 1),
+    ("gn_gsnr_db", np.float64, 1),
 ]
 
 
@@ -348,7 +354,8 @@ class PhyOracleEnv:
 
     def __init__(self, tables, *, num_channels, episode_length, bit_rates, bit_rate_cum, src_cum, dst_cum,
                  arrival_lambda, holding_lambda, pair_table_row, modulation_level, gsnr, link_ends, path_node_off,
-                 path_nodes, grooming=False, defrag_period=None, number_moves=None, metric="cut", seed=41, asan=False):
+                 path_nodes, grooming=False, defrag_period=None, number_moves=None, metric="cut", seed=41, asan=False,
+                 gn_gate=None):
         self.L = _phy_lib(asan)
         self._keep = []
 
@@ -382,6 +389,17 @@ class PhyOracleEnv:
         c.link_ends = keep(link_ends, np.int32)
         c.path_node_off = keep(path_node_off, np.int32)
         c.path_nodes = keep(path_nodes, np.int32)
+        if gn_gate is not None:   # GN-model admission check of the chosen channels (not in the reference: orlg_oracle_phy.h)
+            c.gn_on = 1
+            c.gn_launch_power_w = float(gn_gate["launch_power_w"])
+            c.gn_channel_bandwidth_hz = float(gn_gate["channel_bandwidth_hz"])
+            c.gn_attenuation = float(gn_gate["attenuation_normalized"])
+            c.gn_noise_figure = float(gn_gate["noise_figure"])
+            c.gn_center_frequency_hz = keep(gn_gate["channel_center_frequency_hz"], np.float64)
+            c.gn_link_num_spans = keep(gn_gate["link_num_spans"], np.int32)
+            c.gn_link_span_length_km = keep(gn_gate["link_span_length_km"], np.float64)
+            c.gn_thresholds_db = keep(gn_gate["thresholds_db"], np.float64)
+            c.gn_num_thresholds = len(gn_gate["thresholds_db"])
         self.E, self.Cn = t.num_links, int(num_channels)
         self._t, self._c = t, c
         self.h = self.L.orc_phy_create(C.byref(t), C.byref(c), C.c_uint64(int(seed)))

@@ -13,6 +13,7 @@
  * Pinned bit for bit (floats included) against tests/golden/phy_*.npz recorded from the reference.
  */
 #include "orlg_oracle_phy.h"
+#include "orlg_oracle_osnr.h"
 
 #include "orlg_oracle_common.h"
 
@@ -580,9 +581,51 @@ static void periodic_defragmentation(orc_phy_env *e) {
     free(cands);
 }
 
+/* GN-model GSNR of channel `ch` on path `gid` against the live occupancy (see orc_phy_config): the flattened batch of
+ * orc_gn_osnr -- the restatement of examples/calculate_osnr.py -- is built for ONE check: links = the path's links in path
+ * order, per link its equal spans, per link the lit channels other than `ch` in channel order as interferers. */
+static double gn_gsnr_db(orc_phy_env *e, int gid, int idp, int row, int ch) {
+    const orc_phy_config *g = &e->cfg;
+    const int h0 = e->topo.path_link_off[gid], h1 = e->topo.path_link_off[gid + 1], nl = h1 - h0;
+    int nspans = 0, nsvc = 0;
+    for (int h = h0; h < h1; h++) {
+        const int l = e->topo.path_links[h];
+        nspans += g->gn_link_num_spans[l];
+        for (int c = 0; c < e->C; c++) nsvc += (c != ch && !e->avail[(size_t)l * e->C + c]);
+    }
+    int32_t *link_span_off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl + 1)), *link_svc_off = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nl + 1));
+    double *slen = (double *)malloc(sizeof(double) * (size_t)(nspans + 1)), *satt = (double *)malloc(sizeof(double) * (size_t)(nspans + 1)),
+           *snf = (double *)malloc(sizeof(double) * (size_t)(nspans + 1));
+    double *vbw = (double *)malloc(sizeof(double) * (size_t)(nsvc + 1)), *vcf = (double *)malloc(sizeof(double) * (size_t)(nsvc + 1));
+    int32_t *vse = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nsvc + 1));
+    uint8_t *vself = (uint8_t *)calloc((size_t)(nsvc + 1), 1);
+    int si = 0, vi = 0;
+    for (int h = h0; h < h1; h++) {
+        const int l = e->topo.path_links[h];
+        link_span_off[h - h0] = si; link_svc_off[h - h0] = vi;
+        for (int s = 0; s < g->gn_link_num_spans[l]; s++) {
+            slen[si] = g->gn_link_span_length_km[l]; satt[si] = g->gn_attenuation; snf[si] = g->gn_noise_figure; si++;
+        }
+        for (int c = 0; c < e->C; c++)
+            if (c != ch && !e->avail[(size_t)l * e->C + c]) {
+                int se = g->modulation_level[((size_t)row * e->C + c) * g->k_table + idp];
+                vbw[vi] = g->gn_channel_bandwidth_hz; vcf[vi] = g->gn_center_frequency_hz[c];
+                vse[vi] = se < 1 ? 1 : (se > 6 ? 6 : se); vi++;
+            }
+    }
+    link_span_off[nl] = si; link_svc_off[nl] = vi;
+    int32_t check_link_off[2] = {0, nl};
+    double bw = g->gn_channel_bandwidth_hz, fc = g->gn_center_frequency_hz[ch], pw = g->gn_launch_power_w, out = 0;
+    orc_osnr_batch b = {1, nl, si, vi, check_link_off, link_span_off, link_svc_off, &bw, &fc, &pw, slen, satt, snf, vbw, vcf, vse, vself};
+    orc_gn_osnr(&b, &out);
+    free(link_span_off); free(link_svc_off); free(slen); free(satt); free(snf); free(vbw); free(vcf); free(vse); free(vself);
+    return out;
+}
+
 /* PhyRMSAEnv.step((path, channels)) (phy_rmsa_env.py:272-424) */
 void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out) {
     pservice *s = e->current;
+    double gn_last = NAN;
     s->accepted = 0; s->virtual_layer = 0;
     if (act->path != -2) {
         if (act->path > 10) {
@@ -608,6 +651,17 @@ void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out
             int gid = ppath_gid(e, s->src, s->dst, act->path);
             int free_flag = 1; /* is_path_free_on_channels :1019-1027 */
             for (int i = 0; i < act->n; i++) free_flag &= is_channel_free(e, gid, act->ch[i]);
+            if (free_flag && e->cfg.gn_on) {
+                /* GN gate (not in the reference): every chosen channel must reach the level the table promised */
+                const int row0 = e->cfg.pair_table_row[s->src * e->N + s->dst];
+                for (int i = 0; i < act->n; i++) {
+                    const double gdb = gn_gsnr_db(e, gid, act->path, row0, act->ch[i]);
+                    int level = 0;
+                    for (int t = 0; t < e->cfg.gn_num_thresholds; t++) level += gdb >= e->cfg.gn_thresholds_db[t];
+                    gn_last = gdb;
+                    if (level < act->cap[i]) { free_flag = 0; break; }
+                }
+            }
             if (free_flag) {
                 /* _provision_path :544-623 */
                 int row = e->cfg.pair_table_row[s->src * e->N + s->dst];
@@ -659,6 +713,7 @@ void orc_phy_step(orc_phy_env *e, const orc_phy_action *act, orc_phy_result *out
         out->num_moves = (double)e->counted_moves / 2 + (double)e->counted_moves_groom;
         out->num_moves_groom = e->counted_moves_groom;
         out->num_defrag_cycle = e->counted_defrag_cycles;
+        out->gn_gsnr_db = gn_last;
     }
     e->new_service = 0;
     next_service(e);
@@ -721,6 +776,7 @@ void orc_phy_run(orc_phy_env *e, int policy, int64_t n_steps, int reset_on_done,
             if (tr->num_moves) tr->num_moves[i] = r.num_moves;
             if (tr->num_moves_groom) tr->num_moves_groom[i] = r.num_moves_groom;
             if (tr->num_defrag_cycle) tr->num_defrag_cycle[i] = r.num_defrag_cycle;
+            if (tr->gn_gsnr_db) tr->gn_gsnr_db[i] = r.gn_gsnr_db;
             if (tr->n_running) tr->n_running[i] = e->n_running;
             if (tr->free_total) {
                 int64_t f = 0;

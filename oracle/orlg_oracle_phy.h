@@ -30,6 +30,19 @@ typedef struct orc_phy_config {
     const int32_t *link_ends;        /* [E][2] node ids of every link */
     const int32_t *path_node_off;    /* [num_paths+1] CSR into path_nodes */
     const int32_t *path_nodes;       /* node ids along every path */
+    /* GN-model admission check of the chosen channels (north_star: "GN-model OSNR admission check").  NOT in the reference,
+     * which gates by table only (phy_rmsa_env.py:596): PARITY UNPINNED.  The arithmetic is the restatement of
+     * examples/calculate_osnr.py (orlg_oracle_osnr.c) applied to the LIVE occupancy: a channel chosen on the physical layer is
+     * checked with every lit channel of every link of the path as an interferer (centre frequencies by channel index, the
+     * interferer's modulation taken from the QoT table row of the candidate path), spans = int(length // 80 km) + 1 equal
+     * spans per link (examples/create_topology_gn.py:124); level = number of thresholds met; the service is blocked when a
+     * chosen channel's level falls short of the capacity level the table promised. */
+    int32_t gn_on, gn_num_thresholds;
+    double gn_launch_power_w, gn_channel_bandwidth_hz, gn_attenuation, gn_noise_figure;
+    const double *gn_center_frequency_hz;   /* [channels] */
+    const int32_t *gn_link_num_spans;       /* [E] */
+    const double *gn_link_span_length_km;   /* [E] */
+    const double *gn_thresholds_db;         /* [gn_num_thresholds] ascending */
 } orc_phy_config;
 
 enum { ORC_PHY_POLICY_BMFA = 0, ORC_PHY_POLICY_BMFA_RSS = 1, ORC_PHY_POLICY_SAPFF = 2, ORC_PHY_POLICY_BMFF = 3,
@@ -51,6 +64,7 @@ typedef struct orc_phy_result {
     int64_t total_modulation_level, channels_accepted, path_index, physical_paths;
     double num_moves;       /* counted_moves / 2 + counted_moves_groom (phy_rmsa_env.py:340) */
     int64_t num_moves_groom, num_defrag_cycle;
+    double gn_gsnr_db;      /* GN gate: GSNR of the last channel checked in this step (NaN: no check) */
 } orc_phy_result;
 
 typedef struct orc_phy_trace {
@@ -63,6 +77,7 @@ typedef struct orc_phy_trace {
         *episode_service_blocking_rate, *bit_rate_blocking_rate, *current_time;
     double *num_moves;
     int64_t *num_moves_groom, *num_defrag_cycle;
+    double *gn_gsnr_db;
 } orc_phy_trace;
 
 typedef struct orc_phy_env orc_phy_env;

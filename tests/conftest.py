@@ -107,4 +107,5 @@ def phy_oracle_from_kwargs(topo, tables, env_kwargs, seed=None, asan=False):
                             pair_table_row=topo.pair_table_rows(pairs), modulation_level=mod, gsnr=gsnr,
                             link_ends=topo.link_ends, path_node_off=topo.path_node_off, path_nodes=topo.path_nodes,
                             grooming=kw.get("grooming", True), defrag_period=kw.get("defrag_period"),
-                            number_moves=kw.get("number_moves"), metric=kw.get("metric", "cut"), seed=kw.get("seed", 41) if seed is None else seed, asan=asan)
+                            number_moves=kw.get("number_moves"), metric=kw.get("metric", "cut"), seed=kw.get("seed", 41) if seed is None else seed, asan=asan,
+                            gn_gate=kw.get("gn_gate"))

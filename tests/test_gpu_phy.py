@@ -285,3 +285,43 @@ def test_phy_five_paths_synthetic_tables(policy, device_log_in_oracle):
         o.close()
     assert (tr["act_path"] >= 3).any()   # paths 4 and 5 are used
     env.close()
+
+
+@pytest.mark.parametrize("policy,launch_power_dbm", [("bmfa", 0.0), ("sapff", 2.0)])
+def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_oracle):
+    """GN-model admission check of the chosen channels inside the QoT-aware step (include/orlg.h orlg_gn_gate).  The reference
+    gates by table only: this mode is PARITY UNPINNED by it and pinned to the oracle, which feeds its restatement of
+    examples/calculate_osnr.py with the live occupancy.  Decisions, counters and occupancy must agree exactly, the GSNR values
+    to rtol 1e-9 (the device sums the interferers of a link in a different order: ~1e-15); the gate must actually bind."""
+    from optical_rl_gym_amd import gn_gate_parameters
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    gate = gn_gate_parameters(topo, launch_power_dbm=launch_power_dbm)
+    kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=10, grooming=False, gn_gate=gate)
+    n, batch = 700, 4
+    env = make_env(topo, tables, kw, batch)
+    assert env.last_kernel() .startswith("orlg_phy_kernel<5,true,true>"), env.last_kernel()
+    tr = env.run(policy, n, outputs=("act_path", "channels", "accepted", "gn_gsnr_db", "number_cuts_total"), auto_reset=True)
+    cnt, av = env.counters(), env.available_channels()
+    gate_blocks = 0
+    for i in range(batch):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=10 + i)
+        ot = o.run(policy, n, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["accepted"][:, i], ot["accepted"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        g, og = tr["gn_gsnr_db"][:, i], ot["gn_gsnr_db"]
+        assert np.array_equal(np.isnan(g), np.isnan(og)), i
+        np.testing.assert_allclose(g[~np.isnan(g)], og[~np.isnan(og)], rtol=1e-9, atol=0)
+        assert np.array_equal(av[i], o.available_channels()), i
+        oc = o.counters()
+        for name in oc:
+            assert cnt[name][i] == oc[name], (name, i)
+        gate_blocks += int(((ot["act_path"] >= 0) & (ot["act_path"] < 10) & (ot["accepted"] == 0)).sum())
+        o.close()
+    assert gate_blocks > 20          # the gate rejects some of the table-approved choices ...
+    assert tr["accepted"].mean() > 0.3  # ... and passes others
+    # a virtual-layer service lights nothing new: no check
+    virt = tr["act_path"] >= 20
+    assert np.all(np.isnan(tr["gn_gsnr_db"][virt]))
+    env.close()

@@ -41,3 +41,28 @@ def test_phy_trace_bit_exact(case):
     assert np.array_equal(want, z["average_mod_level"])
     av = env.available_channels()
     assert np.array_equal(np.packbits(av, axis=1, bitorder="little"), z["final_available_channels"])
+
+
+def test_gn_gate_oracle_properties():
+    """The oracle's GN gate (not in the reference: parity unpinned): off by default; with the gate the same requests arrive,
+    every physical-layer choice is checked, some are rejected, and a rejection leaves the occupancy untouched."""
+    import sys
+    from conftest import load_phy_tables, load_topology, phy_oracle_from_kwargs
+    from optical_rl_gym_amd import gn_gate_parameters
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=3, grooming=False)
+    a = phy_oracle_from_kwargs(topo, tables, kw)
+    ta = a.run("bmfa", 400, reset_on_done=True)
+    assert np.all(np.isnan(ta["gn_gsnr_db"]))
+    gate = gn_gate_parameters(topo)
+    assert gate["link_num_spans"].shape == (topo.num_links,) and np.all(gate["link_num_spans"] >= 1)
+    assert np.all(np.diff(gate["thresholds_db"]) > 0) and len(gate["channel_center_frequency_hz"]) == 268
+    b = phy_oracle_from_kwargs(topo, tables, dict(kw, gn_gate=gate))
+    tb = b.run("bmfa", 400, reset_on_done=True)
+    assert np.array_equal(ta["src"], tb["src"]) and np.array_equal(ta["arrival"], tb["arrival"])   # same traffic
+    phys = (tb["act_path"] >= 0) & (tb["act_path"] < 10)
+    assert np.all(~np.isnan(tb["gn_gsnr_db"][phys]))
+    rejected = phys & (tb["accepted"] == 0)
+    assert 5 < rejected.sum() < phys.sum()
+    assert tb["gn_gsnr_db"][phys].min() > 5 and tb["gn_gsnr_db"][phys].max() < 40
+    a.close(); b.close()
