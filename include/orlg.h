@@ -73,7 +73,7 @@ typedef struct orlg_rmsa_config {
 } orlg_rmsa_config;
 
 /* Two step kernels share one state format.  WAVE: one wavefront per environment (every policy).  GROUP: four environments
- * per wavefront, 16 lanes each (every policy but load balancing, which runs on WAVE).  AUTO picks GROUP for a batch larger
+ * per wavefront, 16 lanes each (every policy too).  AUTO picks GROUP for a batch larger
  * than the WAVE kernel's resident wavefronts (4096 on MI355X), WAVE otherwise.  Results are identical bit for bit. */
 enum { ORLG_KERNEL_AUTO = 0, ORLG_KERNEL_WAVE = 1, ORLG_KERNEL_GROUP = 2 };
 

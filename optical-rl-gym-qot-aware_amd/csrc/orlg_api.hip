@@ -305,7 +305,6 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
 
 static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
     if (e->group_mode == ORLG_KERNEL_WAVE || p.mode != ORLG_MODE_STEP) return false;
-    if (p.policy == ORLG_POLICY_LLP) return false;  // the only policy the four-environments-per-wave kernel does not carry
     if (e->group_mode == ORLG_KERNEL_GROUP) return true;
     // AUTO: this kernel once the batch exceeds what the wave-per-environment kernel keeps resident (4096 environments on
     // MI355X) -- long launches (B = 65 536: 1140 vs 630 M env-steps/s) and launches of one step alike (B = 32 768, DeepRMSA

@@ -17,8 +17,7 @@
 // by the whole wave for one environment at a time through a per-wave LDS staging buffer (refill_requests, unchanged).
 //
 // Policies: the first-fit family (shortest path / shortest available path, path-only agent actions), the DeepRMSA block family
-// (its two heuristics and the agent's (path, block) action) and external (path, slot) actions.  Load balancing (llp_ff) runs on the
-// wave-per-environment kernel.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
+// (its two heuristics and the agent's (path, block) action), load balancing (llp_ff) and external (path, slot) actions.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
 #pragma once
 #include "orlg_kernels.hip"
 
@@ -344,11 +343,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                     path0 = a_ok ? a : 0;
                 }
             }
+            // Load balancing (least_loaded_path_first_fit, rmsa_env.py:893-937): of the paths that have a window, the one with the
+            // most free slots on it (ties: the first), its first fit.
+            const bool llp = policy == ORLG_POLICY_LLP;
             const int kmax = (given || policy == ORLG_POLICY_SP || policy == ORLG_POLICY_DEEP_SP) ? 1 : K;
             const int ps = gl / W, w = gl - ps * W;
-            int found = 0x7fffffff;
+            int found = 0x7fffffff, found_key = 0x7fffffff;
             for (int p0 = 0; p0 < kmax; p0 += PP) {
-                if (ballot(act && a_ok && found == 0x7fffffff) == 0ull) break;
+                if (!llp && ballot(act && a_ok && found == 0x7fffffff) == 0ull) break;
                 const int pp = p0 + ps;
                 const bool on = ps < PP && pp < kmax && a_ok;
                 int se_pp, hops_pp;
@@ -378,6 +380,18 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                     }
                 }
                 // key: (path, start slot) decide; the path's slot count and hops ride along in the low bits
+                if (llp) {
+                    // per path, on its first lane: free slots of the path-wide mask and its first fit (none: 0)
+                    const uint32_t fs = seg_add<W>((uint32_t)popc64(x));
+                    const uint32_t fit = seg_max<W>(r ? (uint32_t)(0x7fff - (64 * w + ctz64(r))) : 0u);
+                    const bool head = on && w == 0 && fit != 0u;
+                    const int key = head ? (int)(((1023u - fs) << 4) | (uint32_t)pp) : 0x7fffffff;   // most free slots, then lowest path
+                    const int bk = row_min_i32(key);
+                    const int payload = (head && key == bk) ? ((((pp << 10) | (0x7fff - (int)fit)) << 14) | (n << 4) | hops_pp) : 0x7fffffff;
+                    const int bp = row_min_i32(payload);
+                    if (bk < found_key) { found_key = bk; found = bp; }
+                    continue;
+                }
                 const int cand = r ? (((((path0 + pp) << 10) | (64 * w + ctz64(r))) << 14) | (n << 4) | hops_pp) : 0x7fffffff;
                 const int best = row_min_i32(cand);
                 if (found == 0x7fffffff) found = best;

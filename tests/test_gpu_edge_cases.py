@@ -38,7 +38,7 @@ STEP_KERNEL = "auto"
 
 @pytest.fixture(autouse=True, params=["wave", "group"])
 def step_kernel(request):
-    """Every edge case runs against both step kernels (the four-environments-per-wave kernel hands llp_ff to the other one;
+    """Every edge case runs against both step kernels (the four-environments-per-wave kernel carries llp_ff itself since round 2;
     a shape whose four environments do not fit its LDS budget is served by the other one as well)."""
     global STEP_KERNEL
     STEP_KERNEL = request.param

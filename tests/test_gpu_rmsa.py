@@ -145,6 +145,8 @@ def test_golden_case_vs_reference_and_oracle(case, device_log_in_oracle):
         actions = actions[:n]
     env = make_batched(topo, kw, batch)
     tr = compare_with_oracle(env, topo, kw, policy, n, batch, meta["reset_on_done"], actions=actions)
+    # every policy runs on the kernel that was asked for (load balancing too)
+    assert env.last_kernel().startswith("orlg_rmsa_group_kernel" if STEP_KERNEL == "group" else "orlg_rmsa_kernel"), env.last_kernel()
     # env 0 == the reference's own trace: decisions and integer state exactly, floats to rtol 1e-12
     assert np.array_equal(tr["act_path"][:, 0], z["act_path"][:n])
     assert np.array_equal(tr["act_slot"][:, 0], z["act_slot"][:n])
