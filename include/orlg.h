@@ -53,7 +53,11 @@ typedef struct orlg_topology {
 
 /* Constructor kwargs of RMSAEnv / DeepRMSAEnv (optical_rl_gym/envs/rmsa_env.py:29-53,
  * deeprmsa_env.py:10-32) after the host has turned weights into the cumulative tables CPython's
- * random.choices builds (optical_network_env.py:197-206). */
+ * random.choices builds (optical_network_env.py:197-206).
+ * bit_rate_selection = "discrete" only.  "continuous" (rmsa_env.py:95-104, 655-659) draws the bit rate with rng.randint,
+ * i.e. CPython's _randbelow: rejection sampling that consumes a data-dependent number of MT19937 words per request.  The
+ * arrival generator here produces 64 requests at a time, request j from words [10 j, 10 j + 10) of the stream, which needs a
+ * fixed draw count per request; the host side refuses "continuous" (NotImplementedError) instead of approximating it. */
 typedef struct orlg_rmsa_config {
     int32_t num_slots;        /* num_spectrum_resources, 1..512 */
     int32_t episode_length;
