@@ -49,6 +49,9 @@ __global__ void orlg_phy_clear_kernel(OrlgPhyParams p, int W, int keep_rng) {
         OrlgPhyScalars s;
         memset(&s, 0, sizeof(s));
         s.mt_idx = keep_rng ? p.scal[i].mt_idx : ORLG_MT_N;
+        // pre-generated arrivals are part of the RNG stream: a full reset keeps them
+        s.ring_pos = keep_rng ? p.scal[i].ring_pos : 0;
+        s.ring_cnt = keep_rng ? p.scal[i].ring_cnt : 0;
         p.scal[i] = s;
     }
 }
@@ -259,7 +262,6 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     p.l_occ = off; off = up16(off + p.NW * 8);
     p.l_nbt = off; off = up16(off + ORLG_PHY_NB * 8);
     p.l_nbi = off; off = up16(off + ORLG_PHY_NB * 2);
-    p.l_mt = off; off = up16(off + ORLG_MT_N * 4);
     p.l_scratch = off; off = up16(off + 256 + W * 64 * 8);
     p.l_wsc = off; off = up16(off + (int)sizeof(PhyWaveScalars));
     p.l_wave_bytes = off;
@@ -341,7 +343,8 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         }
         p.tab_bytes = (int32_t)blob.size();
         p.l_outs = p.tab_bytes;
-        p.l_shared_bytes = p.tab_bytes + up16(ORLG_PHY_NUM_OUTS * 8);
+        p.l_mtstage = p.tab_bytes + up16(ORLG_PHY_NUM_OUTS * 8);
+        p.l_shared_bytes = p.l_mtstage + up16(ORLG_MT_N * 4 + 4);
         unsigned char *d_blob;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_blob), blob.size()));
         e->bufs.push_back(d_blob);
@@ -383,6 +386,15 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     TRY(alloc(reinterpret_cast<void **>(&p.qtime), (size_t)batch * Q * 8));
     TRY(alloc(reinterpret_cast<void **>(&p.qrec), (size_t)batch * Q * sizeof(OrlgPhySvc)));
     TRY(alloc(reinterpret_cast<void **>(&p.mt), (size_t)batch * ORLG_MT_N * 4));
+    TRY(alloc(reinterpret_cast<void **>(&p.ring_iat), (size_t)batch * ORLG_RING * 8));
+    TRY(alloc(reinterpret_cast<void **>(&p.ring_ht), (size_t)batch * ORLG_RING * 8));
+    TRY(alloc(reinterpret_cast<void **>(&p.ring_req), (size_t)batch * ORLG_RING * 4));
+    {
+        hipError_t er = hipMemset(p.ring_iat, 0, (size_t)batch * ORLG_RING * 8);
+        if (er == hipSuccess) er = hipMemset(p.ring_ht, 0, (size_t)batch * ORLG_RING * 8);
+        if (er == hipSuccess) er = hipMemset(p.ring_req, 0, (size_t)batch * ORLG_RING * 4);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(er)); }
+    }
     TRY(alloc(reinterpret_cast<void **>(&p.scal), (size_t)batch * sizeof(OrlgPhyScalars)));
     TRY(alloc(reinterpret_cast<void **>(&p.cs), (size_t)batch * N * N * K * p.cs_len * 4));
     TRY(alloc(reinterpret_cast<void **>(&p.cs_n), (size_t)batch * N * N * K));
@@ -602,6 +614,7 @@ static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
     const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
     return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
             {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists},
+            {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8}, {p.ring_req, B * ORLG_RING * 4},
             {p.nv, p.use_nv ? B * p.cpad * sizeof(uint4) : (size_t)0}};
 }
 int64_t orlg_phy_state_size(orlg_phy_env *e) {

@@ -53,7 +53,8 @@ struct __attribute__((aligned(16))) OrlgPhyScalars {
     int64_t episodes_done;
     int32_t n_running, req_src, req_dst, req_br, req_sid, mt_idx, new_service, q_overflow;
     int32_t next_seq, counted_moves, counted_moves_groom, counted_defrag_cycles;  // phy_rmsa_env.py:110-112
-    int32_t pad[6];
+    int32_t ring_pos, ring_cnt;                  // pre-generated arrivals: next entry, entries left (OrlgPhyParams::ring_*)
+    int32_t pad[4];
 };
 static_assert(sizeof(OrlgPhyScalars) == 224, "OrlgPhyScalars layout");
 
@@ -72,7 +73,9 @@ struct OrlgPhyParams {
     uint64_t *occ;          // [B][E*W]
     double *qtime;          // [B][Q]   release times, compact: entries 0..n_running-1 are live
     OrlgPhySvc *qrec;       // [B][Q]
-    uint32_t *mt;           // [B][624]
+    uint32_t *mt;           // [B][624] MT19937 state: fetched only when an environment's arrival ring runs dry
+    double *ring_iat, *ring_ht;   // [B][64] pre-generated inter-arrival / holding times, in RNG stream order (refill_requests)
+    uint32_t *ring_req;           // [B][64] src | dst << 8 | bit-rate index << 16
     OrlgPhyScalars *scal;   // [B]
     uint32_t *cs;           // [B][N*N*K][cs_len] channel_state lists (virtual layer), list order = array order
     uint8_t *cs_n;          // [B][N*N*K] list lengths
@@ -106,7 +109,8 @@ struct OrlgPhyParams {
     void *outs[ORLG_PHY_NUM_OUTS];
     int32_t *err_flag;            // the handle's sticky error word (mapped host memory): a queue / list overflow happened
     // per-wave LDS layout
-    int32_t l_occ, l_nbt, l_nbi, l_mt, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
+    int32_t l_occ, l_nbt, l_nbi, l_scratch, l_wsc, l_wave_bytes, l_shared_bytes, l_outs;
+    int32_t l_mtstage;      // the workgroup's MT19937 staging buffer (2496 B, then its lock word), after the tables
 };
 
 struct PhyWaveScalars {  // LDS
@@ -1138,8 +1142,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
 #pragma unroll
         for (int i = 0; i < ORLG_PHY_NUM_OUTS; ++i)
             if ((int)threadIdx.x == i) reinterpret_cast<u64 *>(smem + p.l_outs)[i] = reinterpret_cast<u64>(p.outs[i]);
+        if (threadIdx.x == 0) *reinterpret_cast<int *>(smem + p.l_mtstage + ORLG_MT_N * 4) = 0;   // the staging buffer's lock
         __syncthreads();
     }
+    // one MT19937 staging buffer per workgroup, handed from wave to wave with a lock word (as orlg_rmsa_group_kernel): the
+    // arrivals of an environment are generated 64 at a time (refill_requests) into a ring in HBM
+    uint32_t *mt_lds = reinterpret_cast<uint32_t *>(smem + p.l_mtstage);
+    int *mt_lock = reinterpret_cast<int *>(smem + p.l_mtstage + ORLG_MT_N * 4);
     const int lane = threadIdx.x & 63;
     const int wib = uni((int)(threadIdx.x >> 6));
     const PhyTab tb = make_phy_tab(smem, p);
@@ -1148,11 +1157,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     NearBuffer nb;
     nb.t = reinterpret_cast<double *>(wb + p.l_nbt);
     nb.qi = reinterpret_cast<uint16_t *>(wb + p.l_nbi);
-    uint32_t *mt = reinterpret_cast<uint32_t *>(wb + p.l_mt);
     uint32_t *scratch = reinterpret_cast<uint32_t *>(wb + p.l_scratch);  // selection lists + per-channel doubles
     PhyWaveScalars *ws = reinterpret_cast<PhyWaveScalars *>(wb + p.l_wsc);
-    Wave wv;  // for draw5
-    wv.lane = lane; wv.mt = mt;
 
     const int E = p.E, C = p.C, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     SEC_DECL
@@ -1194,8 +1200,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     {
         const u64 *g = p.occ + (size_t)env * NW;
         for (int i = lane; i < NW; i += 64) occ[i] = g[i];
-        const uint32_t *gm = p.mt + (size_t)env * ORLG_MT_N;
-        for (int i = lane; i < ORLG_MT_N; i += 64) mt[i] = gm[i];
         if (lane < 8) ws->c[lane] = gs->c[lane];
         if (lane == 0) {
             ws->total_path_index = gs->total_path_index; ws->total_mod = gs->total_mod;
@@ -1213,6 +1217,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     double current_time = gs->current_time;
     int req_src = gs->req_src, req_dst = gs->req_dst, req_br = gs->req_br, req_sid = gs->req_sid;
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
+    int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
     int eproc = (int)gs->c[2];
     wave_sync();
 
@@ -1623,17 +1628,56 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         SEC(7);  // next arrival
         // ============================================================== _next_service (phy_rmsa_env.py:969-1017)
         if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
-            double u[5];
-            draw5(wv, mt_idx, u);
-            double uu = lane == 2 ? u[1] : u[0];
-            double lam = lane == 2 ? p.holding_lambda : p.arrival_lambda;
-            double ex = div_by(-orlg_log(1.0 - uu), lam, recip_refine(lam));
-            double at = current_time + readlane_d(ex, 0);
-            double ht = readlane_d(ex, 2);
+            // the arrival process does not depend on the network state: requests come from the ring of pre-generated arrivals
+            // (five random() draws each, rmsa-style: phy_rmsa_env.py:971-986), refilled 64 at a time when it runs dry
+            if (ring_cnt == 0) {
+                SEC(8);  // refill
+                static_assert(ORLG_MT_N * 4 == 156 * 16, "MT19937 state = 156 rows of 16 bytes");
+                const OrlgPhyParams __attribute__((address_space(4))) *kq =
+                    (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+                const uint4 *g_mt = reinterpret_cast<const uint4 *>(kq->mt + (size_t)env * ORLG_MT_N);
+                uint4 *l_mt = reinterpret_cast<uint4 *>(mt_lds);
+                uint4 m0 = g_mt[lane], m1 = g_mt[lane + 64], m2 = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < 156 - 128) m2 = g_mt[lane + 128];
+                if (lane == 0) {
+                    while (atomicCAS(mt_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                l_mt[lane] = m0; l_mt[lane + 64] = m1;
+                if (lane < 156 - 128) l_mt[lane + 128] = m2;
+                wave_sync();
+                int idx_s = mt_idx;
+                const int got = refill_requests(mt_lds, kq->ring_iat + (size_t)env * ORLG_RING, kq->ring_ht + (size_t)env * ORLG_RING,
+                                                kq->ring_req + (size_t)env * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N, NBR,
+                                                p.arrival_lambda, p.holding_lambda);
+                m0 = l_mt[lane]; m1 = l_mt[lane + 64];
+                if (lane < 156 - 128) m2 = l_mt[lane + 128];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's reads of the buffer are done
+                if (lane == 0) atomicExch(mt_lock, 0);
+                uint4 *o_mt = reinterpret_cast<uint4 *>(kq->mt + (size_t)env * ORLG_MT_N);
+                o_mt[lane] = m0; o_mt[lane + 64] = m1;
+                if (lane < 156 - 128) o_mt[lane + 128] = m2;
+                // the ring entries other lanes wrote are read back below: same CU, the stores only have to be complete
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                wave_sync();
+                mt_idx = idx_s; ring_cnt = got; ring_pos = 0;
+                SEC(7);
+            }
+            double r_iat, r_ht;
+            uint32_t rq;
+            {
+                const OrlgPhyParams __attribute__((address_space(4))) *kq =
+                    (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+                const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+                r_iat = kq->ring_iat[ro]; r_ht = kq->ring_ht[ro]; rq = kq->ring_req[ro];
+            }
+            ring_pos += 1; ring_cnt -= 1;
+            const double at = current_time + readlane_d(r_iat, 0);
+            const double ht = readlane_d(r_ht, 0);
+            rq = (uint32_t)uni((int)rq);
             current_time = at;
-            int src = choice_cum(tb.src_cum, N, u[2], lane);
-            int dst = choice_cum(tb.dst_cum + src * N, N, u[3], lane);
-            int bri = choice_cum(tb.br_cum, NBR, u[4], lane);
+            const int src = (int)(rq & 0xffu), dst = (int)((rq >> 8) & 0xffu), bri = (int)(rq >> 16);
             req_sid = eproc;
             req_src = src; req_dst = dst; req_br = bri;
             new_service = 1;
@@ -1785,8 +1829,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
         u64 *g = kp->occ + (size_t)env * NW;
         for (int i = lane; i < NW; i += 64) g[i] = occ[i];
-        uint32_t *gm = kp->mt + (size_t)env * ORLG_MT_N;
-        for (int i = lane; i < ORLG_MT_N; i += 64) gm[i] = mt[i];
         OrlgPhyScalars *go = kp->scal + env;
         if (lane < 8) go->c[lane] = ws->c[lane];
         if (lane == 0) {
@@ -1799,6 +1841,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             go->n_running = n_running;
             go->req_src = req_src; go->req_dst = req_dst; go->req_br = req_br; go->req_sid = req_sid;
             go->mt_idx = mt_idx; go->new_service = new_service; go->q_overflow = ws->q_overflow;
+            go->ring_pos = ring_pos; go->ring_cnt = ring_cnt;
             if (ws->q_overflow) *kp->err_flag = 1;   // reported by the next entry point that waits for the stream
             go->next_seq = next_seq; go->counted_moves = ws->counted_moves; go->counted_moves_groom = ws->counted_moves_groom;
             go->counted_defrag_cycles = ws->counted_defrag_cycles;
