@@ -244,16 +244,17 @@ typedef struct orlg_phy_config {
     /* calculate_r_cut(modified=True) (phy_rmsa_env.py:1140-1193): per path the links adjacent to its nodes that are
      * not on the path, weight 1 at the end nodes and 2 at interior nodes (CSR over path records) */
     const int32_t *adj_off, *adj_link, *adj_weight;
-    /* Optional, networks of at most 16 nodes: the same metric through per-node free degrees.  With D[v][channel] = number of
-     * links at node v that are free on the channel, sum_j weight_j * available[link_j] = c . D[:, channel] - (the path's own
-     * links, if free) - (chords, if free), c[v] = 1 / 2 / 0 for an end / interior / off-path node; the library keeps D next
-     * to the occupancy (it changes by exactly c when a channel is taken or returned on a path) and evaluates the metric with
-     * byte dot products.  path_node_weights: [num_paths][32] records -- bytes 0..15 c, 16..17 sum of the adjacency weights
-     * (int16), 18..19 c . (path links per node) (int16), 20 number of chords (<= 5), 21..25 chord links, 26..30 chord
-     * weights; node_degree: [16] links per node.  NULL = adjacency lists only (identical results).  D lives in HBM (L2) and
-     * costs a step one read-after-write round trip, so the library uses it when the periodic defragmentation is on (hundreds
-     * of evaluations per cycle) and the LDS adjacency lists otherwise. */
+    /* Optional, networks of at most 16 nodes of at most 15 links each: the same metric through per-node free degrees.  With
+     * D[v][channel] = number of links at node v that are free on the channel, sum_j weight_j * available[link_j] =
+     * c . D[:, channel] - (the path's own links, if free) - (chords, if free), c[v] = 1 / 2 / 0 for an end / interior /
+     * off-path node; the library keeps D next to the occupancy on chip (it changes by exactly c when a channel is taken or
+     * returned on a path; rebuilt from the occupancy at the start of a launch, so it is not part of the saved state) and
+     * evaluates the metric with byte dot products.  path_node_weights: [num_paths][32] records -- bytes 0..15 c, 16..17 sum of
+     * the adjacency weights (int16), 18..19 c . (path links per node) (int16), 20 number of chords (<= 5), 21..25 chord
+     * links, 26..30 chord weights; node_degree: [16] links per node; link_ends: [num_links][2] the two nodes of every link.
+     * Any of them NULL = adjacency lists only (identical results, slower). */
     const uint8_t *path_node_weights, *node_degree;
+    const int32_t *link_ends;
     const struct orlg_gn_gate *gn_gate; /* GN-model admission check of the chosen channels; NULL = off (the reference) */
 } orlg_phy_config;
 
@@ -329,6 +330,9 @@ int orlg_phy_step(orlg_phy_env *env, int32_t policy, int32_t n_steps, const int3
                   const int16_t *act_channels, int32_t auto_reset, const orlg_phy_step_io *io);
 int orlg_phy_last_kernel(orlg_phy_env *env, char *buf, int32_t capacity); /* as orlg_last_kernel */
 int orlg_phy_words_per_link(orlg_phy_env *env);
+/* 1 when the handle evaluates the cut metric through the node-degree vectors (orlg_phy_config::path_node_weights), 0 when
+ * through the adjacency lists (tables missing, more than 16 nodes or 15 links at a node, no room on chip) */
+int orlg_phy_node_vectors(orlg_phy_env *env);
 int orlg_phy_get_requests(orlg_phy_env *env, orlg_request *out /* [B] */);
 int orlg_phy_get_counters(orlg_phy_env *env, orlg_counters *out /* [B] */);
 int orlg_phy_get_current_time(orlg_phy_env *env, double *out /* [B] */);

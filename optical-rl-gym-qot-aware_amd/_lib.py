@@ -61,7 +61,7 @@ class PhyConfig(C.Structure):
                 ("arrival_lambda", C.c_double), ("holding_lambda", C.c_double)] + \
                [(n, C.c_void_p) for n in ("bit_rates", "bit_rate_cum", "src_cum", "dst_cum", "pair_table_row",
                                           "modulation_level", "gsnr", "adj_off", "adj_link", "adj_weight",
-                                          "path_node_weights", "node_degree", "gn_gate")]
+                                          "path_node_weights", "node_degree", "link_ends", "gn_gate")]
 
 
 class GnGate(C.Structure):
@@ -136,6 +136,7 @@ def load(build_if_missing=True):
     L.orlg_phy_reset.argtypes = [vp, i32]
     L.orlg_phy_step.argtypes = [vp, i32, i32, vp, vp, i32, C.POINTER(PhyStepIO)]
     L.orlg_phy_words_per_link.argtypes = [vp]
+    L.orlg_phy_node_vectors.argtypes = [vp]
     for name in ("orlg_phy_get_requests", "orlg_phy_get_counters", "orlg_phy_get_current_time",
                  "orlg_phy_get_num_running", "orlg_phy_get_episode_stats", "orlg_phy_get_occupancy",
                  "orlg_phy_reduce_counters"):
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
     "orlg_simple_matrix_observation", "orlg_simple_matrix_obs_dim", "orlg_host_log",
     "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
-    "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_get_requests", "orlg_phy_get_counters",
+    "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_node_vectors", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
     "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_phy_get_channel_state",
     "orlg_phy_channel_state_capacity", "orlg_gn_osnr", "orlg_state_size", "orlg_save_state", "orlg_load_state",

@@ -43,8 +43,6 @@ __global__ void orlg_phy_clear_kernel(OrlgPhyParams p, int W, int keep_rng) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
     for (size_t i = tid; i < (size_t)p.B * p.NW; i += nth) p.occ[i] = valid_mask(p.C, (int)(i % W));
     for (size_t i = tid; i < (size_t)p.B * p.N * p.N * p.K; i += nth) p.cs_n[i] = 0;
-    if (p.use_nv)   // every link free: the nodes' degrees
-        for (size_t i = tid; i < (size_t)p.B * p.cpad; i += nth) p.nv[i] = p.deg;
     for (size_t i = tid; i < (size_t)p.B; i += nth) {
         OrlgPhyScalars s;
         memset(&s, 0, sizeof(s));
@@ -112,9 +110,8 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
 }
 
 static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
-    // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation (use_nv without it:
-    // ORLG_PHY_NODEVEC=2, tests), 2 + GN-model admission check
-    const int df = p.gn_on ? 2 : (p.defrag_period > 0 || p.use_nv) ? 1 : 0;
+    // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation, 2 + GN-model admission check
+    const int df = p.gn_on ? 2 : p.defrag_period > 0 ? 1 : 0;
     phy_kernel_t k = pick_phy(e->W, df);
     if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -130,6 +127,10 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     int nblocks = (p.B + wpb - 1) / wpb;
     if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
     OrlgPhyParams q = p;
+    // the node-degree vectors are rebuilt from the occupancy by every launch that evaluates the cut metric, and only by those
+    q.use_nv = (p.use_nv && p.mode == ORLG_MODE_STEP &&
+                (p.policy == ORLG_PHY_POLICY_BMFA_CUT || p.policy == ORLG_PHY_POLICY_FAFF || (p.defrag_period > 0 && p.defrag_metric == 0)))
+                   ? 1 : 0;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = (p.mode != ORLG_MODE_STEP || p.n_steps <= 16) ? 1u : 0u;
     if (!q.ticket_stride) e->ticket_base += (uint32_t)p.B;
@@ -341,6 +342,25 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
                 }
             p.t_pathpair = put(pp.data(), pp.size() * 2);
         }
+        // node-degree vectors of the cut metric (include/orlg.h, orlg_phy_config::path_node_weights): D[channel] = 16 nibbles,
+        // links free at every node, in the wave's LDS; ORLG_PHY_NODEVEC=0 keeps the adjacency lists (tests)
+        const char *nvm = getenv("ORLG_PHY_NODEVEC");
+        p.use_nv = (c->path_node_weights && c->node_degree && c->link_ends && N <= 16 && !(nvm && nvm[0] == '0')) ? 1 : 0;
+        if (p.use_nv) {
+            std::vector<uint64_t> lnib(E, 0);
+            int deg[16] = {0};
+            for (int l = 0; l < E && p.use_nv; l++) {
+                const int a = c->link_ends[2 * l], b = c->link_ends[2 * l + 1];
+                if (a < 0 || a >= N || b < 0 || b >= N || a == b) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "link_ends[%d] = (%d, %d)", l, a, b); }
+                lnib[l] = (1ull << (4 * a)) | (1ull << (4 * b));
+                deg[a]++; deg[b]++;
+            }
+            for (int v = 0; v < N; v++) {
+                if (deg[v] != (int)c->node_degree[v]) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "node_degree[%d] = %d, link_ends say %d", v, (int)c->node_degree[v], deg[v]); }
+                if (deg[v] > 15) p.use_nv = 0;   // a nibble per node
+            }
+            if (p.use_nv) p.t_lnib = put(lnib.data(), lnib.size() * 8);
+        }
         p.tab_bytes = (int32_t)blob.size();
         p.l_outs = p.tab_bytes;
         p.l_mtstage = p.tab_bytes + up16(ORLG_PHY_NUM_OUTS * 8);
@@ -366,6 +386,17 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         HIP_TRY(hipMemcpy(d_m, mt.data(), mt.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_g, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
         p.mod_t = d_m; p.gsnr_t = d_g;
+    }
+    if (p.use_nv) {
+        // D takes 8 bytes per channel and wave; it must not cost a resident workgroup (two of ORLG_MAX_WAVES_PER_BLOCK waves
+        // fill the 128-VGPR budget of a CU) -- otherwise the adjacency lists stay
+        const int nv_bytes = up16(C * 8);
+        if (2 * ((size_t)p.l_shared_bytes + (size_t)ORLG_MAX_WAVES_PER_BLOCK * (p.l_wave_bytes + nv_bytes)) <= 160 * 1024) {
+            p.l_nv = p.l_wave_bytes;
+            p.l_wave_bytes += nv_bytes;
+        } else {
+            p.use_nv = 0;
+        }
     }
     {
         int wpb = ORLG_MAX_WAVES_PER_BLOCK;
@@ -403,22 +434,22 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         hipError_t er = hipMemset(p.ticket, 0, 16);
         if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(er)); }
     }
-    // node-degree vectors of the cut metric (include/orlg.h, orlg_phy_config::path_node_weights): D[env][channel] = 16 bytes,
-    // links free at every node; L2-resident, updated whenever a channel is taken or returned on a path
-    // (kept in HBM, D costs a step one read-after-write round trip: it pays where the defragmentation evaluates hundreds of
-    // (service, channel) pairs per cycle; without the defragmentation the adjacency lists in LDS are faster -- measured 207 vs
-    // 181 M env-steps/s on the US14 load-1400 workload; ORLG_PHY_NODEVEC=2 forces it on for tests)
-    const char *nvm = getenv("ORLG_PHY_NODEVEC");
-    const bool nv_force = nvm && nvm[0] == '2';
-    p.use_nv = (c->path_node_weights && c->node_degree && N <= 16 && (p.defrag_period > 0 || nv_force)) ? 1 : 0;
     if (p.use_nv) {
-        TRY(alloc(reinterpret_cast<void **>(&p.nv), (size_t)batch * p.cpad * sizeof(uint4)));
+        // the records with c in the order the byte dot products take it: even nodes, then odd nodes (nv_split)
+        std::vector<uint8_t> rec((size_t)t->num_paths * 32);
+        memcpy(rec.data(), c->path_node_weights, rec.size());
+        for (int g = 0; g < t->num_paths; g++) {
+            const uint8_t *src = c->path_node_weights + (size_t)g * 32;
+            for (int v = 0; v < 16; v++) {
+                if (src[v] > 2) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "path_node_weights[%d][%d] = %d", g, v, (int)src[v]); }
+                rec[(size_t)g * 32 + (v & 1) * 8 + (v >> 1)] = src[v];
+            }
+        }
         uint4 *d_rec = nullptr;
-        TRY(alloc(reinterpret_cast<void **>(&d_rec), (size_t)t->num_paths * 32));
-        hipError_t er = hipMemcpy(d_rec, c->path_node_weights, (size_t)t->num_paths * 32, hipMemcpyHostToDevice);
+        TRY(alloc(reinterpret_cast<void **>(&d_rec), rec.size()));
+        hipError_t er = hipMemcpy(d_rec, rec.data(), rec.size(), hipMemcpyHostToDevice);
         if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "upload of the node weight records: %s", hipGetErrorString(er)); }
         p.nvrec = d_rec;
-        memcpy(&p.deg, c->node_degree, 16);
     }
     if (c->gn_gate) {
         const orlg_gn_gate *g = c->gn_gate;
@@ -576,6 +607,7 @@ int orlg_phy_last_kernel(orlg_phy_env *e, char *buf, int32_t cap) {
     return ORLG_OK;
 }
 int orlg_phy_words_per_link(orlg_phy_env *e) { return e ? e->W : ORLG_ERR_INVALID; }
+int orlg_phy_node_vectors(orlg_phy_env *e) { return e ? e->p.use_nv : ORLG_ERR_INVALID; }
 int orlg_phy_get_requests(orlg_phy_env *e, orlg_request *out) {
     if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->device));
@@ -614,8 +646,7 @@ static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
     const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
     return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
             {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists},
-            {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8}, {p.ring_req, B * ORLG_RING * 4},
-            {p.nv, p.use_nv ? B * p.cpad * sizeof(uint4) : (size_t)0}};
+            {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8}, {p.ring_req, B * ORLG_RING * 4}};
 }
 int64_t orlg_phy_state_size(orlg_phy_env *e) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");

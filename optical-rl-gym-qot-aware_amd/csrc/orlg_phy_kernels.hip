@@ -87,11 +87,12 @@ struct OrlgPhyParams {
     int32_t tab_bytes, t_pair, t_recs, t_bitrates, t_brcum, t_srccum, t_dstcum, t_pairrow, t_adjoff, t_adj, t_sqrt,
         t_plen, t_pathpair, t_masks;
     int32_t use_masks, pad_masks;   // E <= 32: link sets as 32-bit masks (OrlgPathMasks) instead of the adjacency CSR
-    // cut metric through per-node free degrees (orlg_phy_config::path_node_weights), networks of at most 16 nodes
-    uint4 *nv;              // [B][cpad] D[channel]: byte v = links at node v that are free on the channel
-    const uint4 *nvrec;     // [num_paths][2] node weights c (16 bytes) | wsum, cq (int16), chords
-    uint4 deg;              // links per node
-    int32_t use_nv, pad_nv;
+    // cut metric through per-node free degrees (orlg_phy_config::path_node_weights), networks of at most 16 nodes of at most
+    // 15 links each: D[channel] = 16 nibbles (nibble v = links at node v that are free on the channel) in the wave's LDS next
+    // to the occupancy (l_nv), rebuilt from the occupancy at the start of every launch that evaluates the cut metric
+    const uint4 *nvrec;     // [num_paths][2] node weights c (16 bytes: even nodes, then odd nodes) | wsum, cq (int16), chords
+    int32_t use_nv;         // this launch keeps D (the handle has the tables and the launch's policy / defragmentation use the cut metric)
+    int32_t l_nv, t_lnib, pad_nv;   // per-wave LDS offset of D; table: per link, 1 in the nibbles of its two end nodes
     // GN-model admission check of the chosen channels (include/orlg.h orlg_gn_gate), gn_on = 0: off
     int32_t gn_on, gn_nthr;
     double gn_pw, gn_bw, gn_att, gn_nf;
@@ -137,6 +138,7 @@ struct PhyTab {
     const double *path_len;    // [num_paths]
     const uint16_t *path_pair; // [num_paths] a * N + b of the pair (a < b) the record belongs to
     const uint64_t *outs;
+    const uint64_t *lnib;      // [E] 1 << 4 a | 1 << 4 b for a link a - b (only with OrlgPhyParams::use_nv)
 };
 
 DEV PhyTab make_phy_tab(unsigned char *smem, const OrlgPhyParams &p) {
@@ -155,6 +157,7 @@ DEV PhyTab make_phy_tab(unsigned char *smem, const OrlgPhyParams &p) {
     tb.path_pair = reinterpret_cast<const uint16_t *>(smem + p.t_pathpair);
     tb.masks = reinterpret_cast<const OrlgPathMasks *>(smem + p.t_masks);
     tb.outs = reinterpret_cast<const uint64_t *>(smem + p.l_outs);
+    tb.lnib = reinterpret_cast<const uint64_t *>(smem + p.t_lnib);
     return tb;
 }
 
@@ -271,20 +274,38 @@ DEV int nv_chords(const u64 *occ, const NvRec &r, int ch, int W) {
     }
     return s;
 }
-// D[ch] += c (the channel is returned on the path) or -= c (taken): bytes never carry into their neighbours (a node has at
-// least c[v] free / used links among the path's own), so four 32-bit adds do it -- as atomics without return: nothing to
-// wait for, the next reader fences first (nv_fence)
-DEV void nv_update(uint4 *nv, const uint4 &c, int ch, bool returned) {
-    uint32_t *d = reinterpret_cast<uint32_t *>(nv + ch);
-    if (c.x) atomicAdd(d + 0, returned ? c.x : 0u - c.x);
-    if (c.y) atomicAdd(d + 1, returned ? c.y : 0u - c.y);
-    if (c.z) atomicAdd(d + 2, returned ? c.z : 0u - c.z);
-    if (c.w) atomicAdd(d + 3, returned ? c.w : 0u - c.w);
+// D of one channel as the LDS holds it (16 nibbles) -> the byte vectors the dot products take: x = nodes 0 2 4 6, y = nodes
+// 8 10 12 14, z = nodes 1 3 5 7, w = nodes 9 11 13 15 (the records keep c in the same order)
+DEV uint4 nv_split(u64 d) {
+    const uint32_t lo = (uint32_t)d, hi = (uint32_t)(d >> 32);
+    return make_uint4(lo & 0x0f0f0f0fu, hi & 0x0f0f0f0fu, (lo >> 4) & 0x0f0f0f0fu, (hi >> 4) & 0x0f0f0f0fu);
 }
-// a wave reads D entries other lanes of it wrote: the stores have to be complete (same CU: workgroup scope is enough)
-DEV void nv_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+DEV u64 nv_nibbles(const uint4 &c) { return (u64)(c.x | (c.z << 4)) | ((u64)(c.y | (c.w << 4)) << 32); }
+DEV uint4 nv_get(const u64 *dl, int ch, int C) { return nv_split(ch < C ? dl[ch] : 0ull); }
+// D[ch] += c (the channel is returned on the path) or -= c (taken): nibbles never carry into their neighbours (a node has at
+// least c[v] free / used links among the path's own), so one 64-bit LDS add without return does it
+DEV void nv_update(u64 *dl, const uint4 &c, int ch, bool returned) {
+    const u64 nb = nv_nibbles(c);
+    atomicAdd(reinterpret_cast<unsigned long long *>(dl + ch), (unsigned long long)(returned ? nb : 0ull - nb));
+}
+// a wave reads D entries other lanes of it wrote: LDS operations of one wave complete in order
+DEV void nv_fence() { wave_sync(); }
+// D from the occupancy: every free link adds one to the nibbles of its two end nodes
+template <int W>
+DEV void nv_build(u64 *dl, const u64 *occ, const u64 *lnib, int E, int C, int lane) {
+    u64 d[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) d[w] = 0ull;
+    for (int l = 0; l < E; ++l) {
+        const u64 nb = lnib[l];
+        const u64 *rowp = occ + __mul24(l, W);
+#pragma unroll
+        for (int w = 0; w < W; ++w) d[w] += ((rowp[w] >> lane) & 1ull) ? nb : 0ull;
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+        if (64 * w + lane < C) dl[64 * w + lane] = d[w];
+    wave_sync();
 }
 
 // Level and fragmentation metric of the lane's channel in every word of candidate path `idp` (level -1: not free).
@@ -647,7 +668,7 @@ DEV void svc_stash(const SvcPrefetch &pf, OrlgPhySvc *stage, int cnt, int lane) 
 template <int W>
 DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
                              uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
-                             int &next_seq, double current_time, int req_src, int req_dst, int lane, uint4 *gnv, MetricCache &mc SEC_PARAMS) {
+                             int &next_seq, double current_time, int req_src, int req_dst, int lane, u64 *gnv, MetricCache &mc SEC_PARAMS) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
@@ -835,7 +856,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                             // the service holds the channel on its whole path: c . D[ch] counts the free links towards
                             // off-path nodes and the free chords; gain of releasing = 2 * (that - chords) - wsum
                             const NvRec nr = nv_load(p.nvrec, my_gid);
-                            int s = nv_dot(nr.c, gnv[ch]);
+                            int s = nv_dot(nr.c, nv_get(gnv, ch, p.C));
                             if (nr.nchord) s -= nv_chords(occ, nr, ch, W);
                             diff = (double)(2 * s - nr.wsum);
                         } else {
@@ -907,7 +928,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         if (gnv && !rss) {
             nv_fence();
 #pragma unroll
-            for (int w = 0; w < W; ++w) dv[w] = gnv[64 * w + lane];
+            for (int w = 0; w < W; ++w) dv[w] = nv_get(gnv, 64 * w + lane, p.C);
         }
         // one candidate's round data: who it is, and what the tables say about its path
         struct RoundData { double diff; int idx, ch, gid, level_l; int lev_w[W]; uint4 nr0, nr1; const uint8_t *mrow; bool valid; };
@@ -1191,7 +1212,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     nb.horizon = -__longlong_as_double((long long)ORLG_INF_BITS);  // the first look at the queue rebuilds the buffer
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
     uint8_t *gcs_n = p.cs_n + (size_t)env * N * N * K;
-    uint4 *gnv = (DF && p.use_nv) ? p.nv + (size_t)env * p.cpad : nullptr;   // node-degree vectors of the cut metric
+    u64 *gnv = p.use_nv ? reinterpret_cast<u64 *>(wb + p.l_nv) : nullptr;   // node-degree vectors of the cut metric
 
     SEC(1);  // state load
     // ------------------------------------------------------------------ HBM -> LDS
@@ -1220,6 +1241,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     int ring_pos = gs->ring_pos, ring_cnt = gs->ring_cnt;
     int eproc = (int)gs->c[2];
     wave_sync();
+    if (gnv && p.mode == ORLG_MODE_STEP) nv_build<W>(gnv, occ, tb.lnib, E, C, lane);
 
     int *sel_ch = reinterpret_cast<int *>(scratch);            // [16] selected channels
     int *sel_cap = reinterpret_cast<int *>(scratch) + 16;      // [16] their capacity (modulation level)
@@ -1255,7 +1277,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             if (gnv && (p.policy == ORLG_PHY_POLICY_BMFA_CUT || p.policy == ORLG_PHY_POLICY_FAFF)) {
                 nv_fence();
 #pragma unroll
-                for (int w = 0; w < W; ++w) dv[w] = gnv[64 * w + lane];
+                for (int w = 0; w < W; ++w) dv[w] = nv_get(gnv, 64 * w + lane, C);
             }
             const int base = tb.pair_base[req_src * N + req_dst];
             const int row = tb.pair_row[req_src * N + req_dst];

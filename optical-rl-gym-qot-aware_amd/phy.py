@@ -124,10 +124,9 @@ class BatchedPhyRMSAEnv:
         # keeps the adjacency-list evaluation (identical results: tests/test_gpu_phy.py runs both)
         import os
         nv = t.cut_node_tables() if os.environ.get("ORLG_PHY_NODEVEC", "1") != "0" else None
-        # (the library uses them when the periodic defragmentation is on: include/orlg.h; ORLG_PHY_NODEVEC=2 always)
-        self.node_vectors = nv is not None and (bool(defrag_period) or os.environ.get("ORLG_PHY_NODEVEC") == "2")
         if nv is not None:
             cc.path_node_weights, cc.node_degree = keep(nv[0], np.uint8), keep(nv[1], np.uint8)
+            cc.link_ends = keep(np.asarray(t.link_ends, np.int32).reshape(-1, 2), np.int32)
         # GN-model admission check of the chosen channels (osnr.gn_gate_parameters; not in the reference: include/orlg.h)
         self.gn_gate = gn_gate
         if gn_gate is not None:
@@ -154,6 +153,7 @@ class BatchedPhyRMSAEnv:
                                           C.c_uint64(self.rand_seed), int(device), C.byref(h)))
         self.h = h
         self.words_per_link = self.L.orlg_phy_words_per_link(self.h)
+        self.node_vectors = bool(self.L.orlg_phy_node_vectors(self.h))   # cut metric through node-degree vectors (include/orlg.h)
 
     def close(self):
         if getattr(self, "h", None):

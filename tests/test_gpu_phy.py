@@ -30,8 +30,8 @@ def make_env(topo, tables, kw, batch, **extra):
                                        ("phy_us14_s16_sapff_defrag_load3000", 700), ("phy_jpn12_s7_bmff_defrag_rss", 500)])
 def test_phy_policy_vs_oracle_and_reference(case, nmax, device_log_in_oracle, expect_node_vectors=None):
     z, meta = load_golden(case)
-    if expect_node_vectors is None:   # the default: node-degree vectors where the periodic defragmentation runs
-        expect_node_vectors = bool(meta["env_kwargs"].get("defrag_period"))
+    if expect_node_vectors is None:   # the default for networks of at most 16 nodes (US14, JPN12): node-degree vectors
+        expect_node_vectors = True
     topo = load_topology(meta["topology"])
     tables = load_phy_tables(meta["tables"])
     kw = meta["env_kwargs"]
@@ -91,14 +91,6 @@ def test_phy_cut_metric_by_adjacency_lists(case, nmax, device_log_in_oracle, mon
     runs the first; ORLG_PHY_NODEVEC=0 forces the second, held to the same oracle and reference traces."""
     monkeypatch.setenv("ORLG_PHY_NODEVEC", "0")
     test_phy_policy_vs_oracle_and_reference(case, nmax, None, expect_node_vectors=False)
-
-
-@pytest.mark.parametrize("case,nmax", [("phy_us14_s10_bmfa", 500), ("phy_us14_s10_faff", 400), ("phy_jpn12_s3_bmfa", 300),
-                                       ("phy_us14_s10_bmfa_groom", 400)])
-def test_phy_cut_metric_by_node_vectors_without_defragmentation(case, nmax, device_log_in_oracle, monkeypatch):
-    """... and ORLG_PHY_NODEVEC=2 forces the node-degree vectors where the library would not pick them by itself."""
-    monkeypatch.setenv("ORLG_PHY_NODEVEC", "2")
-    test_phy_policy_vs_oracle_and_reference(case, nmax, None, expect_node_vectors=True)
 
 
 def test_phy_info_ratios_match_reference(device_log_in_oracle):
