@@ -386,6 +386,15 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         HIP_TRY(hipMemcpy(d_m, mt.data(), mt.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_g, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
         p.mod_t = d_m; p.gsnr_t = d_g;
+        // the levels of one channel on all K paths next to each other (8 bytes per channel): one load per channel and step
+        std::vector<uint8_t> mk((size_t)c->num_table_rows * p.cpad * 8, 0);
+        for (int r = 0; r < c->num_table_rows; r++)
+            for (int k = 0; k < K; k++)
+                for (int ch = 0; ch < C; ch++) mk[((size_t)r * p.cpad + ch) * 8 + k] = mt[((size_t)r * K + k) * p.cpad + ch];
+        uint8_t *d_k;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_k), mk.size())); e->bufs.push_back(d_k);
+        HIP_TRY(hipMemcpy(d_k, mk.data(), mk.size(), hipMemcpyHostToDevice));
+        p.mod_k = reinterpret_cast<const uint32_t *>(d_k);
     }
     if (p.use_nv) {
         // D takes 8 bytes per channel and wave; it must not cost a resident workgroup (two of ORLG_MAX_WAVES_PER_BLOCK waves

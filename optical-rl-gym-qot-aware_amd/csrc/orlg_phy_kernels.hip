@@ -103,6 +103,7 @@ struct OrlgPhyParams {
     double *cterm;          // [B][cpad] scratch: per-channel term of calculate_total_r_spatial while a launch keeps the per-step
                             // totals incrementally (not part of the state: rebuilt at the start of every launch that needs it)
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
+    const uint32_t *mod_k;  // [num_rows][cpad][2] the same, the levels of one channel on all K paths together (bytes 0..K-1)
     const double *gsnr_t;   // [num_rows*K][cpad]
     // per-call IO
     const int32_t *act_path;      // external actions: [B] path (-2 = blocked)
@@ -248,8 +249,7 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
 // ---- the cut metric through per-node free degrees (OrlgPhyParams::nv).  A path's record: c (16 node weights), wsum = sum of
 // its adjacency weights, cq = c . (path links per node), its chords (links between two path nodes that are not path links).
 struct NvRec { uint4 c; int wsum, cq, nchord; uint32_t cl_lo, cl_hi, cw_lo, cw_hi; };   // chord links / weights: bytes
-DEV NvRec nv_load(const uint4 *nvrec, int gid) {
-    const uint4 a = nvrec[2 * gid], b = nvrec[2 * gid + 1];
+DEV NvRec nv_unpack(const uint4 &a, const uint4 &b) {
     NvRec r;
     r.c = a;
     r.wsum = (int)(int16_t)(b.x & 0xffffu); r.cq = (int)(int16_t)(b.x >> 16);
@@ -258,6 +258,16 @@ DEV NvRec nv_load(const uint4 *nvrec, int gid) {
     r.cl_lo = (b.y >> 8) | (b.z << 24); r.cl_hi = (b.z >> 8) & 0xffu;                 // links 0..3 | link 4
     r.cw_lo = (b.z >> 16) | (b.w << 16); r.cw_hi = (b.w >> 16) & 0xffu;               // weights 0..3 | weight 4
     return r;
+}
+DEV NvRec nv_load(const uint4 *nvrec, int gid) { return nv_unpack(nvrec[2 * gid], nvrec[2 * gid + 1]); }
+// the record of candidate path i out of the lanes that fetched the pair's records together (lane 2 i, 2 i + 1)
+DEV NvRec nv_from_lanes(const uint4 &q, int i) {
+    uint4 a, b;
+    a.x = (uint32_t)__builtin_amdgcn_readlane((int)q.x, 2 * i); a.y = (uint32_t)__builtin_amdgcn_readlane((int)q.y, 2 * i);
+    a.z = (uint32_t)__builtin_amdgcn_readlane((int)q.z, 2 * i); a.w = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 2 * i);
+    b.x = (uint32_t)__builtin_amdgcn_readlane((int)q.x, 2 * i + 1); b.y = (uint32_t)__builtin_amdgcn_readlane((int)q.y, 2 * i + 1);
+    b.z = (uint32_t)__builtin_amdgcn_readlane((int)q.z, 2 * i + 1); b.w = (uint32_t)__builtin_amdgcn_readlane((int)q.w, 2 * i + 1);
+    return nv_unpack(a, b);
 }
 DEV int nv_dot(const uint4 &c, const uint4 &d) {
     uint32_t s = __builtin_amdgcn_udot4(c.x, d.x, 0u, false);
@@ -428,6 +438,77 @@ DEV void phy_row_metrics(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &
             if (fr) { lv[w] = flat_level ? 0 : level; mt[w] = metric; }
         }
     }
+}
+
+// The same for the policies whose metric is an integer (cut: metric_mode 0) or absent (2): level, metric and channel of the
+// lane's channel in one sortable key -- (level << 20) | (metric + 1024) << 9 | (511 - channel), -1 when the channel is not free
+// on the path -- so that "best channel by (level desc, metric desc, channel asc)" is ONE integer maximum over the wave.
+// |metric| <= sum of the adjacency weights < 1024 (checked at creation).
+#define ORLG_PHY_KEY(level, metric, ch) (((level) << 20) | (((metric) + 1024) << 9) | (511 - (ch)))
+// v_cndmask with a wave-uniform lane mask as the condition: lane l takes if_set when bit l of mask is set
+DEV int select_by_lane_mask(u64 mask, int if_set, int if_clear) {
+    int r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+template <int W>
+DEV void phy_row_keys(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, const uint8_t *mrow,
+                      int lane, int metric_mode /* 0 cut, 2 none */, bool flat_level, int (&key)[W],
+                      const uint4 (&dv)[W] /* D of the lane's channels (cut metric with node-degree vectors) */,
+                      const uint32_t (&lvk)[2 * W] /* levels of the lane's channels on all paths (mod_k) */,
+                      const uint4 &nvq /* lane 2 i, 2 i + 1: node record of candidate path i */) {
+    // key = (level << 20) + (metric << 9) + kc, kc = (1024 << 9) | (511 - channel); bits of channels >= C are never set in the
+    // occupancy (valid_mask), so "free on the path" (the lane's bit of the path's word) is the whole condition
+    const int kc0 = (1024 << 9) + 511 - lane;
+    const int lsh = 8 * (idp & 3);
+    if (metric_mode == 0 && p.use_nv) {
+        // cut metric = wsum - 2 * (c . D[channel] - cq - free chords): four byte dot products per channel
+        const NvRec nr = nv_from_lanes(nvq, idp);
+        const int kpath = kc0 + ((nr.wsum + 2 * nr.cq) << 9);
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            int s = nv_dot(nr.c, dv[w]);
+            if (nr.nchord) s -= nv_chords(occ, nr, 64 * w + lane, W);
+            const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[2 * w] : lvk[2 * w + 1]) >> lsh) & 0xffu);
+            const int kk = (lvl << 20) + (kpath - 64 * w) - (s << 10);
+            key[w] = select_by_lane_mask(readlane64(acc, idp * W + w), kk, -1);
+        }
+        return;
+    }
+    int m[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) m[w] = 0;
+    if (metric_mode == 0) {
+        // the adjacency entries sit on lanes (one LDS read), every entry then costs one wave-uniform read of its link's W words
+        const int a0 = tb.adj_off[gid], a1 = tb.adj_off[gid + 1];
+        for (int j0 = a0; j0 < a1; j0 += 64) {
+            const int cnt = a1 - j0 < 64 ? a1 - j0 : 64;
+            const int adjv = lane < cnt ? (int)tb.adj[j0 + lane] : 0;
+            for (int j = 0; j < cnt; ++j) {
+                const int aw = __builtin_amdgcn_readlane(adjv, j);
+                const int wt = aw >> 8;
+                const u64 *rowp = occ + __mul24(aw & 0xff, W);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const int b = (int)((rowp[w] >> lane) & 1ull);
+                    m[w] += wt * (1 - 2 * b);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[2 * w] : lvk[2 * w + 1]) >> lsh) & 0xffu);
+        const int kk = (lvl << 20) + (m[w] << 9) + (kc0 - 64 * w);
+        key[w] = select_by_lane_mask(readlane64(acc, idp * W + w), kk, -1);
+    }
+}
+template <int W>
+DEV int phy_keys_best(const int (&key)[W]) {
+    int h = key[0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) h = key[w] > h ? key[w] : h;
+    return wave_max_i32(h);
 }
 
 // the lane's channel columns of every word, built once per request for all candidate paths (mask mode only)
@@ -1284,6 +1365,21 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             const int demand = tb.bit_rates[req_br];
             const int policy = p.policy;
             int a_path = -2, nsel = 0;
+            // requested now, used after the virtual-layer check as well: the modulation levels of the lane's channels on the K
+            // candidate paths (one or two words per channel) and the paths' node records (lane 2 i, 2 i + 1: path i)
+            uint32_t lvk[2 * W];
+            uint4 nvq = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int w = 0; w < 2 * W; ++w) lvk[w] = 0u;
+            if (policy != ORLG_PHY_POLICY_EXTERNAL && policy != ORLG_PHY_POLICY_BMFA_RSS_METRIC && policy != ORLG_PHY_POLICY_FAFF_RSS) {
+                const uint32_t *mk = p.mod_k + ((size_t)row * p.cpad + lane) * 2;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    lvk[2 * w] = mk[128 * w];
+                    if (K > 4) lvk[2 * w + 1] = mk[128 * w + 1];
+                }
+                if (gnv && lane < 2 * K) nvq = p.nvrec[2 * base + lane];
+            }
 
             if (policy == ORLG_PHY_POLICY_EXTERNAL) {
                 const OrlgPhyParams __attribute__((address_space(4))) *kp =
@@ -1344,81 +1440,149 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     const bool first_row = policy == ORLG_PHY_POLICY_SAPFF || policy == ORLG_PHY_POLICY_SAPBM;
                     const int pp = lane / W, pw = lane - pp * W;
                     const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-                    uint32_t cols[W];
-                    double *r0w = scratch_d;   // free until the per-step outputs
-                    phy_columns<W>(occ, tb, p, lane, metric_mode, cols, r0w);
-                    int head_level[ORLG_PHY_MAX_K];
-                    double head_metric[ORLG_PHY_MAX_K];
-                    unsigned alive = 0;
-                    // the row the first pick below will choose keeps its per-channel (level, metric) values: no second pass
-                    int keep_idp = -1, keep_lv[W], keep_l = -1;
-                    double keep_mt[W], keep_m = 0.0;
+                    if (metric_mode != 1) {
+                        // integer metric: one sortable key per channel (phy_row_keys)
+                        int head_key[ORLG_PHY_MAX_K];
+                        unsigned alive = 0;
+                        // the row the first pick below will choose keeps its per-channel keys: no second pass
+                        int keep_idp = -1, keep_key[W], keep_h = -1;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) { keep_lv[w] = -1; keep_mt[w] = 0.0; }
+                        for (int w = 0; w < W; ++w) keep_key[w] = -1;
 #pragma unroll
-                    for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
-                        head_level[idp] = -1; head_metric[idp] = 0.0;
-                        if (idp < K) {
+                        for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
+                            head_key[idp] = -1;
+                            if (idp < K) {
+                                int key[W];
+                                phy_row_keys<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, key, dv, lvk, nvq);
+                                const int h = phy_keys_best<W>(key);
+                                if (h >= 0) {
+                                    head_key[idp] = h; alive |= 1u << idp;
+                                    // the head's (level, metric): the key without its channel bits
+                                    if (keep_idp < 0 || (!first_row && (h >> 9) > (keep_h >> 9))) {
+                                        keep_idp = idp; keep_h = h;
+#pragma unroll
+                                        for (int w = 0; w < W; ++w) keep_key[w] = key[w];
+                                    }
+                                }
+                            }
+                        }
+                        SEC(4);  // policy: channel selection
+                        for (;;) {
+                            int best = -1, bh = -1;
+#pragma unroll
+                            for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
+                                if (idp < K && ((alive >> idp) & 1u)) {
+                                    if (best < 0 || (!first_row && (head_key[idp] >> 9) > (bh >> 9))) { best = idp; bh = head_key[idp]; }
+                                }
+                            if (best < 0) break;
+                            int key[W];
+                            const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
+                            if (best == keep_idp) {
+#pragma unroll
+                                for (int w = 0; w < W; ++w) key[w] = keep_key[w];
+                                keep_idp = -1;
+                            } else {
+                                phy_row_keys<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, key, dv, lvk, nvq);
+                            }
+                            int unassigned = demand;
+                            nsel = 0;
+                            bool covered = false;
+                            int h = bh;   // the row's head is its first channel
+                            while (nsel < ORLG_PHY_MAX_CH) {
+                                if (h < 0) break;
+                                const int c0 = 511 - (h & 511);
+#pragma unroll
+                                for (int w = 0; w < W; ++w) key[w] = key[w] == h ? -1 : key[w];
+                                const int level = flat ? (int)mrow[c0] : (h >> 20);
+                                unassigned -= level * 100;
+                                const int used = unassigned <= 0 ? level + unassigned / 100 : level;
+                                if (lane == 0) { sel_ch[nsel] = c0; sel_cap[nsel] = level; sel_used[nsel] = used; }
+                                nsel += 1;
+                                if (unassigned <= 0) { covered = true; break; }
+                                h = phy_keys_best<W>(key);
+                            }
+                            if (covered) { a_path = best; break; }
+                            alive &= ~(1u << best);  // sorted_free_channels.pop(row)
+                            nsel = 0;
+                        }
+                    } else {
+                        uint32_t cols[W];
+                        double *r0w = scratch_d;   // free until the per-step outputs
+                        phy_columns<W>(occ, tb, p, lane, metric_mode, cols, r0w);
+                        int head_level[ORLG_PHY_MAX_K];
+                        double head_metric[ORLG_PHY_MAX_K];
+                        unsigned alive = 0;
+                        // the row the first pick below will choose keeps its per-channel (level, metric) values: no second pass
+                        int keep_idp = -1, keep_lv[W], keep_l = -1;
+                        double keep_mt[W], keep_m = 0.0;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) { keep_lv[w] = -1; keep_mt[w] = 0.0; }
+#pragma unroll
+                        for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp) {
+                            head_level[idp] = -1; head_metric[idp] = 0.0;
+                            if (idp < K) {
+                                int lv[W];
+                                double mtr[W];
+                                phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
+                                int bl, bc;
+                                double bm;
+                                phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
+                                if (bl >= 0) {
+                                    head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp;
+                                    if (keep_idp < 0 || (!first_row && (bl > keep_l || (with_metric && bl == keep_l && bm > keep_m)))) {
+                                        keep_idp = idp; keep_l = bl; keep_m = bm;
+#pragma unroll
+                                        for (int w = 0; w < W; ++w) { keep_lv[w] = lv[w]; keep_mt[w] = mtr[w]; }
+                                    }
+                                }
+                            }
+                        }
+                        SEC(4);  // policy: channel selection
+                        for (;;) {
+                            int best = -1, bl = -1;
+                            double bm = 0.0;
+#pragma unroll
+                            for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
+                                if (idp < K && ((alive >> idp) & 1u)) {
+                                    if (best < 0 || (!first_row && (head_level[idp] > bl ||
+                                                                    (with_metric && head_level[idp] == bl && head_metric[idp] > bm)))) {
+                                        best = idp; bl = head_level[idp]; bm = head_metric[idp];
+                                    }
+                                }
+                            if (best < 0) break;
                             int lv[W];
                             double mtr[W];
-                            phy_row_metrics<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
-                            int bl, bc;
-                            double bm;
-                            phy_row_best<W>(lv, mtr, lane, bl, bm, bc);
-                            if (bl >= 0) {
-                                head_level[idp] = bl; head_metric[idp] = bm; alive |= 1u << idp;
-                                if (keep_idp < 0 || (!first_row && (bl > keep_l || (with_metric && bl == keep_l && bm > keep_m)))) {
-                                    keep_idp = idp; keep_l = bl; keep_m = bm;
+                            const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
+                            if (best == keep_idp) {
 #pragma unroll
-                                    for (int w = 0; w < W; ++w) { keep_lv[w] = lv[w]; keep_mt[w] = mtr[w]; }
-                                }
+                                for (int w = 0; w < W; ++w) { lv[w] = keep_lv[w]; mtr[w] = keep_mt[w]; }
+                                keep_idp = -1;
+                            } else {
+                                phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
                             }
-                        }
-                    }
-                    SEC(4);  // policy: channel selection
-                    for (;;) {
-                        int best = -1, bl = -1;
-                        double bm = 0.0;
+                            int unassigned = demand;
+                            nsel = 0;
+                            bool covered = false;
+                            while (nsel < ORLG_PHY_MAX_CH) {
+                                int l0, c0;
+                                double m0;
+                                phy_row_best<W>(lv, mtr, lane, l0, m0, c0);
+                                if (l0 < 0) break;
 #pragma unroll
-                        for (int idp = 0; idp < ORLG_PHY_MAX_K; ++idp)
-                            if (idp < K && ((alive >> idp) & 1u)) {
-                                if (best < 0 || (!first_row && (head_level[idp] > bl ||
-                                                                (with_metric && head_level[idp] == bl && head_metric[idp] > bm)))) {
-                                    best = idp; bl = head_level[idp]; bm = head_metric[idp];
-                                }
+                                for (int w = 0; w < W; ++w)
+                                    if (64 * w + lane == c0) lv[w] = -1;
+                                const int level = flat ? (int)mrow[c0] : l0;
+                                unassigned -= level * 100;
+                                const int used = unassigned <= 0 ? level + unassigned / 100 : level;
+                                if (lane == 0) { sel_ch[nsel] = c0; sel_cap[nsel] = level; sel_used[nsel] = used; }
+                                nsel += 1;
+                                if (unassigned <= 0) { covered = true; break; }
                             }
-                        if (best < 0) break;
-                        int lv[W];
-                        double mtr[W];
-                        const uint8_t *mrow = p.mod_t + (size_t)(row * K + best) * p.cpad;
-                        if (best == keep_idp) {
-#pragma unroll
-                            for (int w = 0; w < W; ++w) { lv[w] = keep_lv[w]; mtr[w] = keep_mt[w]; }
-                            keep_idp = -1;
-                        } else {
-                            phy_row_metrics<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, lv, mtr, cols, r0w, dv);
+                            if (covered) { a_path = best; break; }
+                            alive &= ~(1u << best);  // sorted_free_channels.pop(row)
+                            nsel = 0;
                         }
-                        int unassigned = demand;
-                        nsel = 0;
-                        bool covered = false;
-                        while (nsel < ORLG_PHY_MAX_CH) {
-                            int l0, c0;
-                            double m0;
-                            phy_row_best<W>(lv, mtr, lane, l0, m0, c0);
-                            if (l0 < 0) break;
-#pragma unroll
-                            for (int w = 0; w < W; ++w)
-                                if (64 * w + lane == c0) lv[w] = -1;
-                            const int level = flat ? (int)mrow[c0] : l0;
-                            unassigned -= level * 100;
-                            const int used = unassigned <= 0 ? level + unassigned / 100 : level;
-                            if (lane == 0) { sel_ch[nsel] = c0; sel_cap[nsel] = level; sel_used[nsel] = used; }
-                            nsel += 1;
-                            if (unassigned <= 0) { covered = true; break; }
-                        }
-                        if (covered) { a_path = best; break; }
-                        alive &= ~(1u << best);  // sorted_free_channels.pop(row)
-                        nsel = 0;
+                
                     }
                 }
                 wave_sync();
