@@ -1233,7 +1233,47 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
 // DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
 // without it run the other one, whose registers are not shared with code they never execute
 // GN: ... and the one that also carries the GN-model admission check (orlg_gn_gate)
-template <int W, bool DF, bool GN>
+// ---- the release of the NEXT step, looked up ahead.  The arrival times come from the pre-generated ring, so at the start of a
+// step the wave already knows the time of the following arrival and can look for the service that will be released first then;
+// its record (and, once that has arrived, its channel_state list and the queue's last record, which will take its place) are
+// requested long before the release needs them.  The release loop still finds its victims by itself: the prefetched data is
+// used only when the loop's first victim is the one looked up (anything else falls back to plain loads).
+typedef int orlg_v4i __attribute__((ext_vector_type(4)));
+#define ORLG_GPTR(T, v) ((T __attribute__((address_space(1))) *)(v))   // an output array: global memory, not a generic pointer
+struct ReleaseAhead {
+    int q;            // queue index of the looked-up service, -1: none
+    uint32_t rec;     // lane < 12: dword `lane` of its record
+    int key;          // its channel_state list (valid when cs_ok)
+    bool cs_ok;       // the list below was requested (the service holds partially used channels)
+    uint32_t cs_e;    // lane i: entry i
+    int cs_n;         // list length (as loaded: a byte on every lane)
+    int last;         // queue index of the last record when `lrec` was requested, -1: none
+    uint32_t lrec;    // lane < 12: dword `lane` of the last record; lanes 12, 13: its release time
+};
+DEV uint32_t rec_dword(const OrlgPhySvc *grec, int q, int lane) {
+    return lane < 12 ? reinterpret_cast<const uint32_t *>(grec + q)[lane] : 0u;
+}
+static_assert(sizeof(OrlgPhySvc) == 48 && ORLG_PHY_MAX_CH == 14, "record = 12 dwords: arrival, seq, gid | nch | flags, 14 channels, pad");
+// first service due at `time` among the near buffer's entries (earliest release, ties: lowest queue index)
+DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, int &vpos) {
+    double best_t = 0.0;
+    victim = -1; vpos = -1;
+    for (int c0 = 0; c0 < nb.n; c0 += 64) {
+        const int c = c0 + lane;
+        const double tq = c < nb.n ? nb.t[c] : __longlong_as_double((long long)ORLG_INF_BITS);
+        const int qi = c < nb.n ? (int)nb.qi[c] : 0;
+        u64 m = ballot(tq <= time);
+        while (m) {
+            const int l = ctz64(m);
+            m &= m - 1;
+            const double tt = readlane_d(tq, l);
+            const int qq = __builtin_amdgcn_readlane(qi, l);
+            if (victim < 0 || tt < best_t || (tt == best_t && qq < victim)) { best_t = tt; victim = qq; vpos = c0 + l; }
+        }
+    }
+}
+
+template <int W, bool DF, bool GN, bool RSSP /* the policy sorts channels by the RSS metric (bmfa_rss, faff_rss) */>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_phy_kernel(const OrlgPhyParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     {
@@ -1346,10 +1386,36 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
     }
 
+    ReleaseAhead ra;
+    ra.q = -1; ra.rec = 0u; ra.key = 0; ra.cs_ok = false; ra.cs_e = 0u; ra.cs_n = 0; ra.last = -1; ra.lrec = 0u;
+    // the next ring entry, requested one step ahead: lanes 0, 1 inter-arrival time, lanes 2, 3 holding time, lane 4 the request
+    uint32_t pf_ring = 0u;
+    bool pf_ring_ok = false;
+    auto ring_fetch = [&]() {
+        pf_ring_ok = ring_cnt > 0;
+        if (pf_ring_ok) {
+            const OrlgPhyParams __attribute__((address_space(4))) *kq =
+                (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+            const size_t ro = (size_t)env * ORLG_RING + ring_pos;
+            const uint32_t *src = lane < 2 ? reinterpret_cast<const uint32_t *>(kq->ring_iat + ro) + lane
+                                : lane < 4 ? reinterpret_cast<const uint32_t *>(kq->ring_ht + ro) + (lane - 2) : kq->ring_req + ro;
+            if (lane < 5) pf_ring = *src;
+        }
+    };
+    if (p.mode == ORLG_MODE_STEP) ring_fetch();
     const int n_iter = p.mode == ORLG_MODE_STEP ? p.n_steps : 1;
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy: virtual layer
         if (p.mode == ORLG_MODE_STEP) {
+            // the release the next arrival will trigger first, looked up now (ReleaseAhead): its record is on its way while the
+            // policy runs
+            ra.q = -1; ra.cs_ok = false; ra.last = -1;
+            if (pf_ring_ok && current_time <= nb.horizon) {
+                const double next_time = current_time + __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 1), __builtin_amdgcn_readlane((int)pf_ring, 0));
+                int vq, vp;
+                nb_first_due(nb, next_time, lane, vq, vp);
+                if (vq >= 0) { ra.q = vq; ra.rec = rec_dword(grec, vq, lane); }
+            }
             // D of the lane's channels (cut metric): requested first, used after the virtual-layer check; it serves every candidate
             // path of the request.  (The fence: entries other lanes rewrote since the last look -- their stores are long done.)
             uint4 dv[W];
@@ -1371,7 +1437,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             uint4 nvq = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
             for (int w = 0; w < 2 * W; ++w) lvk[w] = 0u;
-            if (policy != ORLG_PHY_POLICY_EXTERNAL && policy != ORLG_PHY_POLICY_BMFA_RSS_METRIC && policy != ORLG_PHY_POLICY_FAFF_RSS) {
+            if (!RSSP && policy != ORLG_PHY_POLICY_EXTERNAL) {
                 const uint32_t *mk = p.mod_k + ((size_t)row * p.cpad + lane) * 2;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
@@ -1434,13 +1500,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     //   sapbm:           sorted(row, key=(-level, channel)),  first non-empty row
                     //   sapff:           sorted(row, key=channel),            first non-empty row
                     //   faff / faff_rss: sorted(row, key=-metric),            row with the best head metric (ties: lower index)
-                    const int metric_mode = (policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_FAFF) ? 0
-                                            : (policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC || policy == ORLG_PHY_POLICY_FAFF_RSS) ? 1 : 2;
+                    const int metric_mode = RSSP ? 1 : (policy == ORLG_PHY_POLICY_BMFA_CUT || policy == ORLG_PHY_POLICY_FAFF) ? 0 : 2;
                     const bool flat = policy == ORLG_PHY_POLICY_SAPFF || faff;  // the level is not a sort key
                     const bool first_row = policy == ORLG_PHY_POLICY_SAPFF || policy == ORLG_PHY_POLICY_SAPBM;
                     const int pp = lane / W, pw = lane - pp * W;
                     const u64 acc = path_word<W>(occ, tb.recs, base + pp, pw, pp < K);
-                    if (metric_mode != 1) {
+                    if constexpr (!RSSP) {
                         // integer metric: one sortable key per channel (phy_row_keys)
                         int head_key[ORLG_PHY_MAX_K];
                         unsigned alive = 0;
@@ -1646,6 +1711,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 const int gid = base + a_path;
                 const OrlgPathRec *rec = tb.recs + gid;
                 const int hops = rec->hops;
+                // requested now, used after the checks: the GSNR of the chosen channels (lane i: channel i) and, when a channel is
+                // only partly used, the channel_state list it will join
+                const int cs_key_p = (req_src * N + req_dst) * K + a_path;
+                const int my_ch = lane < nsel ? sel_ch[lane] : 0;
+                const bool ch_ok = lane < nsel && my_ch >= 0 && my_ch < C;
+                const double my_gsnr = ch_ok ? p.gsnr_t[(size_t)(row * K + a_path) * p.cpad + my_ch] : 0.0;
+                const bool any_partial_p = ballot(lane < nsel && sel_used[lane] != sel_cap[lane]) != 0ull;
+                CsList csl;
+                csl.e = 0u; csl.n = 0; csl.cap = p.cs_len;
+                if (any_partial_p) csl = cs_load(gcs, gcs_n, cs_key_p, lane, p.cs_len);
                 // is_path_free_on_channels (:1019-1027): lanes = (channel, hop) pairs
                 bool bad = false;
                 for (int i = lane; i < nsel * hops; i += 64) {
@@ -1682,30 +1757,33 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         for (int ci = 0; ci < nsel; ++ci) mc_after(occ, mc, sel_ch[ci], lane);
                     }
                     if (gnv) {   // the nodes of the path lose free links on these channels
-                        const uint4 cv = p.nvrec[2 * gid];
-                        if (lane < nsel) nv_update(gnv, cv, sel_ch[lane], false);
+                        uint4 cv;
+                        if (!RSSP && policy != ORLG_PHY_POLICY_EXTERNAL) {   // the pair's records are on lanes (nvq)
+                            cv.x = (uint32_t)__builtin_amdgcn_readlane((int)nvq.x, 2 * a_path); cv.y = (uint32_t)__builtin_amdgcn_readlane((int)nvq.y, 2 * a_path);
+                            cv.z = (uint32_t)__builtin_amdgcn_readlane((int)nvq.z, 2 * a_path); cv.w = (uint32_t)__builtin_amdgcn_readlane((int)nvq.w, 2 * a_path);
+                        } else {
+                            cv = p.nvrec[2 * gid];
+                        }
+                        if (lane < nsel) nv_update(gnv, cv, my_ch, false);
                     }
                     // partially used channels enter channel_state (:600-602)
-                    {
-                        const int key = (req_src * N + req_dst) * K + a_path;
-                        CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
-                        bool changed = false, overflow = false;
+                    if (any_partial_p) {
+                        bool overflow = false;
                         for (int ci = 0; ci < nsel; ++ci) {
                             const int cap = sel_cap[ci], used = sel_used[ci];
                             if (used != cap) {
-                                if (!cs_append(l, cs_pack(sel_ch[ci], used, cap - used, cap), lane)) overflow = true;
-                                changed = true;
+                                if (!cs_append(csl, cs_pack(sel_ch[ci], used, cap - used, cap), lane)) overflow = true;
                             }
                         }
-                        if (changed) cs_store(gcs, gcs_n, key, l, lane);
+                        cs_store(gcs, gcs_n, cs_key_p, csl, lane);
                         if (overflow && lane == 0) ws->q_overflow |= 4;
                     }
                     // statistics, in channel order (the GSNR sum is a float64 accumulation)
+                    double tg = ws->total_gsnr;
+                    for (int ci = 0; ci < nsel; ++ci) tg += readlane_d(my_gsnr, ci);
                     if (lane == 0) {
-                        const double *grow = p.gsnr_t + (size_t)(row * K + a_path) * p.cpad;
-                        double tg = ws->total_gsnr;
                         long long tm = ws->total_mod;
-                        for (int ci = 0; ci < nsel; ++ci) { tg += grow[sel_ch[ci]]; tm += sel_cap[ci]; }
+                        for (int ci = 0; ci < nsel; ++ci) tm += sel_cap[ci];
                         ws->total_gsnr = tg; ws->total_mod = tm;
                         ws->channels_accepted += nsel;
                         // _service_acceptance(False) (:767-778)
@@ -1750,6 +1828,26 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
             }
 
+            // the looked-up release, second stage: its record has arrived by now -- its channel_state list (only if it shares
+            // channels) and the queue's last record, which will move into its place
+            if (ra.q >= 0) {
+                const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)ra.rec, 3);
+                const int rgid = (int)(d3 & 0xffffu), rnch = (int)((d3 >> 16) & 0xffu), rflags = (int)(d3 >> 24);
+                // channel i: dword 4 + i / 2, half i & 1; partial = bit 14
+                const bool lane_ch = lane >= 4 && lane < 4 + ((rnch + 1) >> 1);
+                const uint32_t pm = (2 * (lane - 4) + 1 < rnch) ? 0x40004000u : 0x00004000u;
+                if (ballot(lane_ch && (ra.rec & pm) != 0u) != 0ull) {
+                    ra.key = svc_key(tb, N, K, rgid, rflags);
+                    ra.cs_ok = true;
+                    ra.cs_n = (int)gcs_n[ra.key];
+                    ra.cs_e = lane < p.cs_len ? gcs[(size_t)ra.key * p.cs_len + lane] : 0u;
+                }
+                if (n_running >= 2 && ra.q != n_running - 1) {
+                    ra.last = n_running - 1;
+                    ra.lrec = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + ra.last)[lane]
+                                        : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + ra.last)[lane - 12] : 0u;
+                }
+            }
             SEC(6);  // outputs
             // per-step outputs
             if (p.out_mask) {
@@ -1774,28 +1872,28 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, want_c, want_r, p.use_masks != 0, cuts, rss, tr_unused);
                 }
                 if (om & (1 << ORLG_PHY_OUT_CHANNELS)) {
-                    int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CHANNELS]) + o * ORLG_PHY_MAX_CH;
+                    auto oc = ORLG_GPTR(int16_t, tb.outs[ORLG_PHY_OUT_CHANNELS]) + o * ORLG_PHY_MAX_CH;
                     if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_ch[lane] : (int16_t)-1;
                 }
                 if (om & (1 << ORLG_PHY_OUT_CH_USED)) {
-                    int16_t *oc = reinterpret_cast<int16_t *>(tb.outs[ORLG_PHY_OUT_CH_USED]) + o * ORLG_PHY_MAX_CH;
+                    auto oc = ORLG_GPTR(int16_t, tb.outs[ORLG_PHY_OUT_CH_USED]) + o * ORLG_PHY_MAX_CH;
                     if (lane < ORLG_PHY_MAX_CH) oc[lane] = lane < nsel ? (int16_t)sel_used[lane] : (int16_t)0;
                 }
                 if (lane == 0) {
-                    if (om & (1 << ORLG_PHY_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_PATH])[o] = a_path;
-                    if (om & (1 << ORLG_PHY_OUT_NCH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_NCH])[o] = nsel;
-                    if (om & (1 << ORLG_PHY_OUT_ACCEPTED)) reinterpret_cast<uint8_t *>(tb.outs[ORLG_PHY_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
+                    if (om & (1 << ORLG_PHY_OUT_PATH)) ORLG_GPTR(int32_t, tb.outs[ORLG_PHY_OUT_PATH])[o] = a_path;
+                    if (om & (1 << ORLG_PHY_OUT_NCH)) ORLG_GPTR(int32_t, tb.outs[ORLG_PHY_OUT_NCH])[o] = nsel;
+                    if (om & (1 << ORLG_PHY_OUT_ACCEPTED)) ORLG_GPTR(uint8_t, tb.outs[ORLG_PHY_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
                     if (om & (1 << ORLG_PHY_OUT_REQUEST))
-                        reinterpret_cast<int4 *>(tb.outs[ORLG_PHY_OUT_REQUEST])[o] = make_int4(req_sid, req_src, req_dst, demand);
-                    if (om & (1 << ORLG_PHY_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_ARRIVAL])[o] = ws->req_arrival;
-                    if (om & (1 << ORLG_PHY_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_HOLDING])[o] = ws->req_holding;
+                        ORLG_GPTR(orlg_v4i, tb.outs[ORLG_PHY_OUT_REQUEST])[o] = orlg_v4i{req_sid, req_src, req_dst, demand};
+                    if (om & (1 << ORLG_PHY_OUT_ARRIVAL)) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_ARRIVAL])[o] = ws->req_arrival;
+                    if (om & (1 << ORLG_PHY_OUT_HOLDING)) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_HOLDING])[o] = ws->req_holding;
                     if (om & (1 << ORLG_PHY_OUT_DEFRAG)) {  // the counters as the info dict sees them: before this step's defragmentation
-                        int32_t *od = reinterpret_cast<int32_t *>(tb.outs[ORLG_PHY_OUT_DEFRAG]) + o * 3;
+                        auto od = ORLG_GPTR(int32_t, tb.outs[ORLG_PHY_OUT_DEFRAG]) + o * 3;
                         od[0] = ws->counted_moves; od[1] = ws->counted_moves_groom; od[2] = ws->counted_defrag_cycles;
                     }
-                    if (om & (1 << ORLG_PHY_OUT_GN)) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_GN])[o] = gn_last;
-                    if (want_c) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_CUTS])[o] = cuts;
-                    if (want_r) reinterpret_cast<double *>(tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
+                    if (om & (1 << ORLG_PHY_OUT_GN)) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_GN])[o] = gn_last;
+                    if (want_c) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_CUTS])[o] = cuts;
+                    if (want_r) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
                 }
             }
             new_service = 0;
@@ -1850,18 +1948,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 mt_idx = idx_s; ring_cnt = got; ring_pos = 0;
                 SEC(7);
             }
-            double r_iat, r_ht;
-            uint32_t rq;
-            {
-                const OrlgPhyParams __attribute__((address_space(4))) *kq =
-                    (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
-                const size_t ro = (size_t)env * ORLG_RING + ring_pos;
-                r_iat = kq->ring_iat[ro]; r_ht = kq->ring_ht[ro]; rq = kq->ring_req[ro];
-            }
+            if (!pf_ring_ok) ring_fetch();   // the ring was empty when this step began (or the launch does not step)
+            const double r_iat = __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 1), __builtin_amdgcn_readlane((int)pf_ring, 0));
+            const double ht = __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 3), __builtin_amdgcn_readlane((int)pf_ring, 2));
+            const uint32_t rq = (uint32_t)__builtin_amdgcn_readlane((int)pf_ring, 4);
             ring_pos += 1; ring_cnt -= 1;
-            const double at = current_time + readlane_d(r_iat, 0);
-            const double ht = readlane_d(r_ht, 0);
-            rq = (uint32_t)uni((int)rq);
+            if (p.mode == ORLG_MODE_STEP) ring_fetch();   // the entry of the next step
+            else pf_ring_ok = false;
+            const double at = current_time + r_iat;
             current_time = at;
             const int src = (int)(rq & 0xffu), dst = (int)((rq >> 8) & 0xffu), bri = (int)(rq >> 16);
             req_sid = eproc;
@@ -1881,47 +1975,52 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 if (!nb_rebuild(nb, gq, n_running, current_time, p.holding_lambda, lane) && lane == 0) ws->q_overflow |= 8;
             }
             for (;;) {
-                double best_t = 0.0;
-                int victim = -1, vpos = -1;
-                for (int c0 = 0; c0 < nb.n; c0 += 64) {
-                    const int c = c0 + lane;
-                    const double tq = c < nb.n ? nb.t[c] : __longlong_as_double((long long)ORLG_INF_BITS);
-                    const int qi = c < nb.n ? (int)nb.qi[c] : 0;
-                    u64 m = ballot(tq <= current_time);
-                    while (m) {
-                        const int l = ctz64(m);
-                        m &= m - 1;
-                        const double tt = readlane_d(tq, l);
-                        const int qq = __builtin_amdgcn_readlane(qi, l);
-                        if (victim < 0 || tt < best_t || (tt == best_t && qq < victim)) { best_t = tt; victim = qq; vpos = c0 + l; }
-                    }
-                }
+                int victim, vpos;
+                nb_first_due(nb, current_time, lane, victim, vpos);
                 if (victim < 0) break;
                 SEC(10);  // release apply
-                const OrlgPhySvc sv = grec[victim];
-                const OrlgPathRec *rec = tb.recs + sv.gid;
-                const int pair = tb.path_pair[sv.gid];
+                const bool ahead = victim == ra.q;   // the service looked up at the start of the step: its data is here
+                // the record stays on lanes (lane i < 12: dword i): no array of channels in private memory
+                const uint32_t rv = ahead ? ra.rec : rec_dword(grec, victim, lane);
+                const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)rv, 3);
+                const int sv_gid = (int)(d3 & 0xffffu), sv_nch = (int)((d3 >> 16) & 0xffu), sv_flags = (int)(d3 >> 24);
+                // lane i < nch: channel i of the service (channel | used << 9 | partial << 14)
+                const uint32_t pair_dw = (uint32_t)__shfl((int)rv, 4 + (lane >> 1));
+                const int raw_l = lane < sv_nch ? (int)((pair_dw >> (16 * (lane & 1))) & 0xffffu) : 0;
+#ifdef ORLG_SECTIONS
+                if (!DF) { if (sv_gid == 0xffff) ws->q_overflow |= 64; SEC(11); }
+#endif
+                const OrlgPathRec *rec = tb.recs + sv_gid;
+                const int pair = tb.path_pair[sv_gid];
                 const int pa = pair / N, pb = pair - pa * N;
-                const int ssrc = (sv.flags & 2) ? pb : pa, sdst = (sv.flags & 2) ? pa : pb;
-                const int idp = (int)sv.gid - tb.pair_base[pair];
+                const int ssrc = (sv_flags & 2) ? pb : pa, sdst = (sv_flags & 2) ? pa : pb;
+                const int idp = sv_gid - tb.pair_base[pair];
                 const int key = (ssrc * N + sdst) * K + idp;
                 u64 freemask[W];  // channels to return on every link of the path
+                const bool any_partial = ballot(lane < sv_nch && (raw_l & (1 << 14))) != 0ull;
 #pragma unroll
                 for (int w = 0; w < W; ++w) freemask[w] = 0ull;
-                bool any_partial = false;
-                for (int ci = 0; ci < sv.nch; ++ci) {
-                    const int raw = sv.ch[ci];
-                    if (raw & (1 << 14)) { any_partial = true; } else {
+                for (int ci = 0; ci < sv_nch; ++ci) {
+                    const int raw = __builtin_amdgcn_readlane(raw_l, ci);
+                    if (!(raw & (1 << 14))) {
                         const int ch = raw & 0x1ff;
 #pragma unroll
                         for (int w = 0; w < W; ++w)
                             if ((ch >> 6) == w) freemask[w] |= 1ull << (ch & 63);
                     }
                 }
+                // the path's node weights: requested now, used after the channel_state update
+                uint4 cv_rel = make_uint4(0u, 0u, 0u, 0u);
+                if (gnv) cv_rel = p.nvrec[2 * sv_gid];
                 if (any_partial) {
-                    CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
-                    for (int ci = 0; ci < sv.nch; ++ci) {
-                        const int raw = sv.ch[ci];
+                    CsList l;
+                    if (ahead && ra.cs_ok && ra.key == key) {
+                        l.n = uni(ra.cs_n); l.cap = p.cs_len; l.e = lane < l.n ? ra.cs_e : 0u;
+                    } else {
+                        l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+                    }
+                    for (int ci = 0; ci < sv_nch; ++ci) {
+                        const int raw = __builtin_amdgcn_readlane(raw_l, ci);
                         if (!(raw & (1 << 14))) continue;
                         const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
                         const int q = cs_find(l, ch, lane);
@@ -1938,6 +2037,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                     cs_store(gcs, gcs_n, key, l, lane);
                 }
+#ifdef ORLG_SECTIONS
+                if (!DF) SEC(12);
+#endif
                 if (mc.on) {
 #pragma unroll
                     for (int w = 0; w < W; ++w)
@@ -1955,15 +2057,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_after(occ, mc, 64 * w + ctz64(m), lane);
                 }
                 if (gnv) {   // the returned channels: lane = channel of word w, the nodes of the path gain free links
-                    const uint4 cv = p.nvrec[2 * (int)sv.gid];
 #pragma unroll
                     for (int w = 0; w < W; ++w)
-                        if (freemask[w] != 0ull && ((freemask[w] >> lane) & 1ull)) nv_update(gnv, cv, 64 * w + lane, true);
+                        if (freemask[w] != 0ull && ((freemask[w] >> lane) & 1ull)) nv_update(gnv, cv_rel, 64 * w + lane, true);
                 }
+#ifdef ORLG_SECTIONS
+                if (!DF) SEC(14);
+#endif
                 // swap-remove: the last live entry takes the victim's place (its near-buffer entry follows it) ...
                 n_running -= 1;
                 if (victim != n_running) {
-                    if (lane == 0) {
+                    if (ahead && ra.last == n_running) {
+                        if (lane < 12) reinterpret_cast<uint32_t *>(grec + victim)[lane] = ra.lrec;
+                        else if (lane < 14) reinterpret_cast<uint32_t *>(gq + victim)[lane - 12] = ra.lrec;
+                    } else if (lane == 0) {
                         gq[victim] = gq[n_running];
                         grec[victim] = grec[n_running];
                     }
@@ -1977,6 +2084,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 nb.n -= 1;
                 if (vpos != nb.n && lane == 0) { nb.t[vpos] = nb.t[nb.n]; nb.qi[vpos] = nb.qi[nb.n]; }
                 wave_sync();
+                ra.q = -1; ra.last = -1;   // the queue has changed: what was looked up ahead is stale
+#ifdef ORLG_SECTIONS
+                if (!DF) SEC(10);
+#endif
             }
         }
 
@@ -1992,7 +2103,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         if (p.mode == ORLG_MODE_STEP) {
             const bool done = (eproc == p.episode_length);
             if (lane == 0 && (p.out_mask & (1 << ORLG_PHY_OUT_DONE)))
-                reinterpret_cast<uint8_t *>(tb.outs[ORLG_PHY_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
+                ORLG_GPTR(uint8_t, tb.outs[ORLG_PHY_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
             if (done && p.auto_reset) {
                 eproc = 1;
                 if (lane == 0) {

@@ -291,7 +291,7 @@ def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_o
     kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=10, grooming=False, gn_gate=gate)
     n, batch = 700, 4
     env = make_env(topo, tables, kw, batch)
-    assert env.last_kernel() .startswith("orlg_phy_kernel<5,true,true>"), env.last_kernel()
+    assert env.last_kernel().startswith("orlg_phy_kernel<5,true,true,"), env.last_kernel()
     tr = env.run(policy, n, outputs=("act_path", "channels", "accepted", "gn_gsnr_db", "number_cuts_total"), auto_reset=True)
     cnt, av = env.counters(), env.available_channels()
     gate_blocks = 0
