@@ -465,10 +465,21 @@ DEV void phy_row_keys(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, 
         // cut metric = wsum - 2 * (c . D[channel] - cq - free chords): four byte dot products per channel
         const NvRec nr = nv_from_lanes(nvq, idp);
         const int kpath = kc0 + ((nr.wsum + 2 * nr.cq) << 9);
+        int chs[W];   // weighted free chords of the lane's channels: per chord the link's W words in one go
+#pragma unroll
+        for (int w = 0; w < W; ++w) chs[w] = 0;
+        for (int q = 0; q < nr.nchord; ++q) {
+            const int cl = (int)((q < 4 ? nr.cl_lo >> (8 * q) : nr.cl_hi) & 0xffu), cw = (int)((q < 4 ? nr.cw_lo >> (8 * q) : nr.cw_hi) & 0xffu);
+            const u64 *rowp = occ + __mul24(cl, W);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const u64 x = rowp[w];
+                chs[w] += select_by_lane_mask(readlane64(x, 0), cw, 0);
+            }
+        }
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-            int s = nv_dot(nr.c, dv[w]);
-            if (nr.nchord) s -= nv_chords(occ, nr, 64 * w + lane, W);
+            int s = nv_dot(nr.c, dv[w]) - chs[w];
             const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[2 * w] : lvk[2 * w + 1]) >> lsh) & 0xffu);
             const int kk = (lvl << 20) + (kpath - 64 * w) - (s << 10);
             key[w] = select_by_lane_mask(readlane64(acc, idp * W + w), kk, -1);
@@ -1247,6 +1258,7 @@ struct ReleaseAhead {
     bool cs_ok;       // the list below was requested (the service holds partially used channels)
     uint32_t cs_e;    // lane i: entry i
     int cs_n;         // list length (as loaded: a byte on every lane)
+    uint32_t cvl;     // lane < 4: dword `lane` of its path's node weights (cut metric with node-degree vectors)
     int last;         // queue index of the last record when `lrec` was requested, -1: none
     uint32_t lrec;    // lane < 12: dword `lane` of the last record; lanes 12, 13: its release time
 };
@@ -1254,6 +1266,18 @@ DEV uint32_t rec_dword(const OrlgPhySvc *grec, int q, int lane) {
     return lane < 12 ? reinterpret_cast<const uint32_t *>(grec + q)[lane] : 0u;
 }
 static_assert(sizeof(OrlgPhySvc) == 48 && ORLG_PHY_MAX_CH == 14, "record = 12 dwords: arrival, seq, gid | nch | flags, 14 channels, pad");
+// a new record written by lanes: lane i < nch holds channel i's halfword (0xffff beyond), dwords 4..10 pair them up
+DEV uint32_t rec_store(OrlgPhySvc *dst, const double *arrival_lds, uint32_t seq, int gid, int nch, int flags, uint32_t hw, int lane) {
+    const int j = lane >= 4 ? lane - 4 : 0;
+    const uint32_t h0 = (uint32_t)__shfl((int)hw, 2 * j), h1 = (uint32_t)__shfl((int)hw, 2 * j + 1);
+    uint32_t v = h0 | (h1 << 16);
+    if (lane < 2) v = reinterpret_cast<const uint32_t *>(arrival_lds)[lane];
+    if (lane == 2) v = seq;
+    if (lane == 3) v = (uint32_t)gid | ((uint32_t)nch << 16) | ((uint32_t)flags << 24);
+    if (lane == 11) v = 0u;
+    if (lane < 12) reinterpret_cast<uint32_t *>(dst)[lane] = v;
+    return v;
+}
 // first service due at `time` among the near buffer's entries (earliest release, ties: lowest queue index)
 DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, int &vpos) {
     double best_t = 0.0;
@@ -1387,7 +1411,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     }
 
     ReleaseAhead ra;
-    ra.q = -1; ra.rec = 0u; ra.key = 0; ra.cs_ok = false; ra.cs_e = 0u; ra.cs_n = 0; ra.last = -1; ra.lrec = 0u;
+    ra.q = -1; ra.rec = 0u; ra.key = 0; ra.cs_ok = false; ra.cs_e = 0u; ra.cs_n = 0; ra.last = -1; ra.lrec = 0u; ra.cvl = 0u;
     // the next ring entry, requested one step ahead: lanes 0, 1 inter-arrival time, lanes 2, 3 holding time, lane 4 the request
     uint32_t pf_ring = 0u;
     bool pf_ring_ok = false;
@@ -1654,6 +1678,30 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             }
 
             SEC(5);  // provision
+            // the looked-up release, second stage: its record has arrived by now (the policy waited for loads requested earlier);
+            // its channel_state list (only if it shares channels), its path's node weights and the queue's last record, which
+            // will move into its place, are requested BEFORE this step's stores go out -- a wait for a load also waits for every
+            // store issued before it
+            int prov_key = -1;   // channel_state list this step's provisioning rewrites
+            if (ra.q >= 0) {
+                const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)ra.rec, 3);
+                const int rgid = (int)(d3 & 0xffffu), rnch = (int)((d3 >> 16) & 0xffu), rflags = (int)(d3 >> 24);
+                // channel i: dword 4 + i / 2, half i & 1; partial = bit 14
+                const bool lane_ch = lane >= 4 && lane < 4 + ((rnch + 1) >> 1);
+                const uint32_t pm = (2 * (lane - 4) + 1 < rnch) ? 0x40004000u : 0x00004000u;
+                if (ballot(lane_ch && (ra.rec & pm) != 0u) != 0ull) {
+                    ra.key = svc_key(tb, N, K, rgid, rflags);
+                    ra.cs_ok = true;
+                    ra.cs_n = (int)gcs_n[ra.key];
+                    ra.cs_e = lane < p.cs_len ? gcs[(size_t)ra.key * p.cs_len + lane] : 0u;
+                }
+                if (gnv && lane < 4) ra.cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * rgid)[lane];
+                if (n_running >= 2 && ra.q != n_running - 1) {
+                    ra.last = n_running - 1;
+                    ra.lrec = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + ra.last)[lane]
+                                        : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + ra.last)[lane - 12] : 0u;
+                }
+            }
             // ========================================================== PhyRMSAEnv.step (phy_rmsa_env.py:272-351)
             bool accepted = false;
             double gn_last = __longlong_as_double(0x7ff8000000000000ll);   // NaN: no GN check in this step
@@ -1675,21 +1723,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
                 if (ok) {
                     cs_store(gcs, gcs_n, key, l, lane);
+                    prov_key = key;
                     if (lane == 0) { ws->c[1] += 1; ws->c[3] += 1; ws->c[5] += demand; ws->c[7] += demand; }
                     accepted = true;
                     if (n_running < Q) {
-                        if (lane == 0) {
-                            gq[n_running] = ws->req_arrival + ws->req_holding;
-                            OrlgPhySvc sv;
-                            sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
-                            sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(1 | (dirbit ? 2 : 0));
-                            for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
-                                sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) | (1 << 14)) : 0xffffu;
-                            grec[n_running] = sv;
-                        }
+                        if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
+                        const uint32_t newrec = rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, 1 | (dirbit ? 2 : 0),
+                                  lane < nsel ? (uint32_t)(sel_ch[lane] | (sel_used[lane] << 9) | (1 << 14)) : 0xffffu, lane);
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
+                            if (ra.q >= 0) {   // the new record is the queue's last one now
+                                ra.last = qidx;
+                                ra.lrec = lane < 12 ? newrec : lane == 12 ? (uint32_t)__double2loint(rel) : (uint32_t)__double2hiint(rel);
+                            }
                             n_running += 1;
                             if (rel <= nb.horizon) {
                                 if (nb.n < ORLG_PHY_NB) {
@@ -1717,20 +1764,25 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 const int my_ch = lane < nsel ? sel_ch[lane] : 0;
                 const bool ch_ok = lane < nsel && my_ch >= 0 && my_ch < C;
                 const double my_gsnr = ch_ok ? p.gsnr_t[(size_t)(row * K + a_path) * p.cpad + my_ch] : 0.0;
-                const bool any_partial_p = ballot(lane < nsel && sel_used[lane] != sel_cap[lane]) != 0ull;
+                const int my_used = lane < nsel ? sel_used[lane] : 0, my_cap = lane < nsel ? sel_cap[lane] : 0;
+                const bool any_partial_p = ballot(lane < nsel && my_used != my_cap) != 0ull;
                 CsList csl;
                 csl.e = 0u; csl.n = 0; csl.cap = p.cs_len;
                 if (any_partial_p) csl = cs_load(gcs, gcs_n, cs_key_p, lane, p.cs_len);
                 // is_path_free_on_channels (:1019-1027): lanes = (channel, hop) pairs
-                bool bad = false;
-                for (int i = lane; i < nsel * hops; i += 64) {
-                    const int ci = i / hops, h = i - ci * hops;
-                    const int ch = sel_ch[ci];
-                    if (ch < 0 || ch >= C) { bad = true; } else {
-                        bad = bad || !((occ[(int)rec->link[h] * W + (ch >> 6)] >> (ch & 63)) & 1ull);
+                // (the heuristics pick among the channels that are free on the path right now: only external actions need the look)
+                bool pass = true;
+                if (policy == ORLG_PHY_POLICY_EXTERNAL) {
+                    bool bad = false;
+                    for (int i = lane; i < nsel * hops; i += 64) {
+                        const int ci = i / hops, h = i - ci * hops;
+                        const int ch = sel_ch[ci];
+                        if (ch < 0 || ch >= C) { bad = true; } else {
+                            bad = bad || !((occ[(int)rec->link[h] * W + (ch >> 6)] >> (ch & 63)) & 1ull);
+                        }
                     }
+                    pass = ballot(bad) == 0ull;
                 }
-                bool pass = ballot(bad) == 0ull;
                 if (GN && p.gn_on && pass) {
                     // GN gate (not in the reference): every chosen channel must reach the level the table promised
                     const uint8_t *mrow_g = p.mod_t + (size_t)(row * K + a_path) * p.cpad;
@@ -1745,11 +1797,21 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 if (pass) {
                     // _provision_path (:544-623): one lane per hop clears the channels on its link
                     for (int ci = 0; ci < nsel; ++ci) mc_before(occ, mc, sel_ch[ci], lane);
-                    if (lane < hops) {
-                        u64 *rowp = occ + (int)rec->link[lane] * W;
+                    {
+                        u64 clr[W];   // the chosen channels as masks (wave-uniform): one read-modify-write per word and link
+#pragma unroll
+                        for (int w = 0; w < W; ++w) clr[w] = 0ull;
                         for (int ci = 0; ci < nsel; ++ci) {
-                            const int ch = sel_ch[ci];
-                            rowp[ch >> 6] &= ~(1ull << (ch & 63));
+                            const int ch = __builtin_amdgcn_readlane(my_ch, ci);
+#pragma unroll
+                            for (int w = 0; w < W; ++w)
+                                if ((ch >> 6) == w) clr[w] |= 1ull << (ch & 63);
+                        }
+                        if (lane < hops) {
+                            u64 *rowp = occ + (int)rec->link[lane] * W;
+#pragma unroll
+                            for (int w = 0; w < W; ++w)
+                                if (clr[w] != 0ull) rowp[w] &= ~clr[w];
                         }
                     }
                     if (mc.on) {
@@ -1766,18 +1828,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         }
                         if (lane < nsel) nv_update(gnv, cv, my_ch, false);
                     }
-                    // partially used channels enter channel_state (:600-602)
-                    if (any_partial_p) {
-                        bool overflow = false;
-                        for (int ci = 0; ci < nsel; ++ci) {
-                            const int cap = sel_cap[ci], used = sel_used[ci];
-                            if (used != cap) {
-                                if (!cs_append(csl, cs_pack(sel_ch[ci], used, cap - used, cap), lane)) overflow = true;
-                            }
-                        }
-                        cs_store(gcs, gcs_n, cs_key_p, csl, lane);
-                        if (overflow && lane == 0) ws->q_overflow |= 4;
-                    }
                     // statistics, in channel order (the GSNR sum is a float64 accumulation)
                     double tg = ws->total_gsnr;
                     for (int ci = 0; ci < nsel; ++ci) tg += readlane_d(my_gsnr, ci);
@@ -1792,23 +1842,33 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         ws->total_path_index += a_path + 1;
                         ws->physical_accepted += 1;
                     }
+                    // (the loads above are consumed: from here on stores)
+                    // partially used channels enter channel_state (:600-602)
+                    if (any_partial_p) {
+                        bool overflow = false;
+                        for (int ci = 0; ci < nsel; ++ci) {
+                            const int cap = sel_cap[ci], used = sel_used[ci];
+                            if (used != cap) {
+                                if (!cs_append(csl, cs_pack(sel_ch[ci], used, cap - used, cap), lane)) overflow = true;
+                            }
+                        }
+                        cs_store(gcs, gcs_n, cs_key_p, csl, lane);
+                        prov_key = cs_key_p;
+                        if (overflow && lane == 0) ws->q_overflow |= 4;
+                    }
                     accepted = true;
                     // _add_release: compact queue, append at n_running
                     if (n_running < Q) {
-                        if (lane == 0) {
-                            gq[n_running] = ws->req_arrival + ws->req_holding;
-                            OrlgPhySvc sv;
-                            sv.arrival = ws->req_arrival; sv.seq = (uint32_t)next_seq;
-                            sv.gid = (uint16_t)gid; sv.nch = (uint8_t)nsel; sv.flags = (uint8_t)(dirbit ? 2 : 0);
-                            for (int ci = 0; ci < ORLG_PHY_MAX_CH; ++ci)
-                                sv.ch[ci] = ci < nsel ? (uint16_t)(sel_ch[ci] | (sel_used[ci] << 9) |
-                                                                   ((sel_used[ci] != sel_cap[ci] ? 1 : 0) << 14))
-                                                      : 0xffffu;
-                            grec[n_running] = sv;
-                        }
+                        if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
+                        const uint32_t newrec = rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, dirbit ? 2 : 0,
+                                  lane < nsel ? (uint32_t)(my_ch | (my_used << 9) | ((my_used != my_cap ? 1 : 0) << 14)) : 0xffffu, lane);
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
+                            if (ra.q >= 0) {   // the new record is the queue's last one now
+                                ra.last = qidx;
+                                ra.lrec = lane < 12 ? newrec : lane == 12 ? (uint32_t)__double2loint(rel) : (uint32_t)__double2hiint(rel);
+                            }
                             n_running += 1;
                             if (rel <= nb.horizon) {
                                 if (nb.n < ORLG_PHY_NB) {
@@ -1828,26 +1888,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
             }
 
-            // the looked-up release, second stage: its record has arrived by now -- its channel_state list (only if it shares
-            // channels) and the queue's last record, which will move into its place
-            if (ra.q >= 0) {
-                const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)ra.rec, 3);
-                const int rgid = (int)(d3 & 0xffffu), rnch = (int)((d3 >> 16) & 0xffu), rflags = (int)(d3 >> 24);
-                // channel i: dword 4 + i / 2, half i & 1; partial = bit 14
-                const bool lane_ch = lane >= 4 && lane < 4 + ((rnch + 1) >> 1);
-                const uint32_t pm = (2 * (lane - 4) + 1 < rnch) ? 0x40004000u : 0x00004000u;
-                if (ballot(lane_ch && (ra.rec & pm) != 0u) != 0ull) {
-                    ra.key = svc_key(tb, N, K, rgid, rflags);
-                    ra.cs_ok = true;
-                    ra.cs_n = (int)gcs_n[ra.key];
-                    ra.cs_e = lane < p.cs_len ? gcs[(size_t)ra.key * p.cs_len + lane] : 0u;
-                }
-                if (n_running >= 2 && ra.q != n_running - 1) {
-                    ra.last = n_running - 1;
-                    ra.lrec = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + ra.last)[lane]
-                                        : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + ra.last)[lane - 12] : 0u;
-                }
-            }
+            if (ra.cs_ok && ra.key == prov_key) ra.cs_ok = false;   // this step rewrote the list that was requested ahead
             SEC(6);  // outputs
             // per-step outputs
             if (p.out_mask) {
@@ -1987,9 +2028,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 // lane i < nch: channel i of the service (channel | used << 9 | partial << 14)
                 const uint32_t pair_dw = (uint32_t)__shfl((int)rv, 4 + (lane >> 1));
                 const int raw_l = lane < sv_nch ? (int)((pair_dw >> (16 * (lane & 1))) & 0xffffu) : 0;
-#ifdef ORLG_SECTIONS
-                if (!DF) { if (sv_gid == 0xffff) ws->q_overflow |= 64; SEC(11); }
-#endif
                 const OrlgPathRec *rec = tb.recs + sv_gid;
                 const int pair = tb.path_pair[sv_gid];
                 const int pa = pair / N, pb = pair - pa * N;
@@ -2009,13 +2047,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             if ((ch >> 6) == w) freemask[w] |= 1ull << (ch & 63);
                     }
                 }
-                // the path's node weights: requested now, used after the channel_state update
-                uint4 cv_rel = make_uint4(0u, 0u, 0u, 0u);
-                if (gnv) cv_rel = p.nvrec[2 * sv_gid];
+                // every load of this release first (what was not requested ahead), every store last
+                const bool move_last = victim != n_running - 1;
+                const bool last_ahead = ahead && ra.last == n_running - 1;
+                uint32_t lastv = ra.lrec;
+                if (move_last && !last_ahead)
+                    lastv = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + (n_running - 1))[lane]
+                                      : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + (n_running - 1))[lane - 12] : 0u;
+                uint32_t cvl = ra.cvl;
+                if (gnv && !ahead && lane < 4) cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * sv_gid)[lane];
+                CsList l;
+                l.e = 0u; l.n = 0; l.cap = p.cs_len;
                 if (any_partial) {
-                    CsList l;
                     if (ahead && ra.cs_ok && ra.key == key) {
-                        l.n = uni(ra.cs_n); l.cap = p.cs_len; l.e = lane < l.n ? ra.cs_e : 0u;
+                        l.n = uni(ra.cs_n); l.e = lane < l.n ? ra.cs_e : 0u;
                     } else {
                         l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
                     }
@@ -2035,11 +2080,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             cs_append(l, cs_pack(ch, cs_used(en) - mine, cs_free(en) + mine, cs_cap(en)), lane);
                         }
                     }
-                    cs_store(gcs, gcs_n, key, l, lane);
                 }
-#ifdef ORLG_SECTIONS
-                if (!DF) SEC(12);
-#endif
                 if (mc.on) {
 #pragma unroll
                     for (int w = 0; w < W; ++w)
@@ -2057,23 +2098,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_after(occ, mc, 64 * w + ctz64(m), lane);
                 }
                 if (gnv) {   // the returned channels: lane = channel of word w, the nodes of the path gain free links
+                    uint4 cv_rel;
+                    cv_rel.x = (uint32_t)__builtin_amdgcn_readlane((int)cvl, 0); cv_rel.y = (uint32_t)__builtin_amdgcn_readlane((int)cvl, 1);
+                    cv_rel.z = (uint32_t)__builtin_amdgcn_readlane((int)cvl, 2); cv_rel.w = (uint32_t)__builtin_amdgcn_readlane((int)cvl, 3);
 #pragma unroll
                     for (int w = 0; w < W; ++w)
                         if (freemask[w] != 0ull && ((freemask[w] >> lane) & 1ull)) nv_update(gnv, cv_rel, 64 * w + lane, true);
                 }
-#ifdef ORLG_SECTIONS
-                if (!DF) SEC(14);
-#endif
-                // swap-remove: the last live entry takes the victim's place (its near-buffer entry follows it) ...
+                // the stores: the rewritten channel_state list ...
+                if (any_partial) cs_store(gcs, gcs_n, key, l, lane);
+                // ... and the swap-remove: the last live entry takes the victim's place (its near-buffer entry follows it) ...
                 n_running -= 1;
-                if (victim != n_running) {
-                    if (ahead && ra.last == n_running) {
-                        if (lane < 12) reinterpret_cast<uint32_t *>(grec + victim)[lane] = ra.lrec;
-                        else if (lane < 14) reinterpret_cast<uint32_t *>(gq + victim)[lane - 12] = ra.lrec;
-                    } else if (lane == 0) {
-                        gq[victim] = gq[n_running];
-                        grec[victim] = grec[n_running];
-                    }
+                if (move_last) {
+                    if (lane < 12) reinterpret_cast<uint32_t *>(grec + victim)[lane] = lastv;
+                    else if (lane < 14) reinterpret_cast<uint32_t *>(gq + victim)[lane - 12] = lastv;
                     for (int c0 = 0; c0 < nb.n; c0 += 64) {
                         const int c = c0 + lane;
                         if (c < nb.n && (int)nb.qi[c] == n_running) nb.qi[c] = (uint16_t)victim;
@@ -2085,9 +2123,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 if (vpos != nb.n && lane == 0) { nb.t[vpos] = nb.t[nb.n]; nb.qi[vpos] = nb.qi[nb.n]; }
                 wave_sync();
                 ra.q = -1; ra.last = -1;   // the queue has changed: what was looked up ahead is stale
-#ifdef ORLG_SECTIONS
-                if (!DF) SEC(10);
-#endif
             }
         }
 

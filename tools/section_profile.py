@@ -36,7 +36,7 @@ def main():
                                 defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None)
         names = ["idle/ticket", "state load", "policy: virtual layer", "policy: row metrics", "policy: channel selection", "provision",
                  "outputs", "next arrival + RNG", "defrag: grooming walk", "release: buffer / rebuild", "release apply (+ next scan)",
-                 "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", ""]
+                 "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", "dev"]
         env.run(args.phy, 3000, auto_reset=True)
         L = _lib.load()
         out = (C.c_ulonglong * 16)()
@@ -45,7 +45,7 @@ def main():
         env.synchronize()
         L.orlg_debug_sections(out, 1)
         tot = sum(out)
-        res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(15) if names[i]}
+        res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(16) if names[i]}
         res["cycles_per_env_step"] = tot / (args.batch * args.steps)
         print(json.dumps({"kernel": "phy", "policy": args.phy, "defrag": args.defrag, "percent_of_wave_cycles": res}))
         return
