@@ -193,6 +193,17 @@ DEV double rss_of_column(uint32_t col, const double *sqrt_tab) {
     return ORLG_FDIV(sqrt_tab[sq], (double)(sm + 1));
 }
 
+// float64 sum of n per-channel terms in channel order (the reference accumulates them one by one: phy_rmsa_env.py:1117) out
+// of an LDS array whose entries from n up to the next multiple of 8 are zero: 8 terms per LDS round trip
+DEV double ordered_sum_lds(const double *terms, int n) {
+    double r = 0.0;
+    const double2 *sd2 = reinterpret_cast<const double2 *>(terms);
+    for (int c8 = 0; c8 < (n + 7) / 8; ++c8) {
+        const double2 a0 = sd2[4 * c8], a1 = sd2[4 * c8 + 1], a2 = sd2[4 * c8 + 2], a3 = sd2[4 * c8 + 3];
+        r += a0.x; r += a0.y; r += a1.x; r += a1.y; r += a2.x; r += a2.y; r += a3.x; r += a3.y;
+    }
+    return r;
+}
 // _calculate_total_cuts (phy_rmsa_env.py:1195-1203) and calculate_total_r_spatial (:1110-1121): run-length statistics of
 // every channel's column along the link axis.  Lane = channel; the link loop is wave-uniform.
 template <int W>
@@ -238,9 +249,7 @@ DEV void phy_column_metrics(const u64 *occ, const double *sqrt_tab, int E, int C
     if (want_rss) {
         wave_sync();
         // the reference accumulates the per-channel terms in channel order in float64 (phy_rmsa_env.py:1117)
-        double r = 0.0;
-        for (int ch = 0; ch < C; ++ch) r += scratch_d[ch];
-        rss_out = r / (double)C;
+        rss_out = ordered_sum_lds(scratch_d, C) / (double)C;   // terms of channels >= C are zero (written above)
         wave_sync();
     }
     (void)want_cuts;
@@ -1899,14 +1908,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 if (mc.on) {
                     cuts = (double)mc.total_runs / (double)C;
                     if (want_r) {
-                        // the terms other lanes rewrote are complete; through LDS, then the reference's channel-order sum
+                        // the terms lane 0 rewrote in this step are complete (same wave: in order).  Through LDS, then the
+                        // reference's channel-order float64 sum: 8 terms per LDS round trip (one trip per term made this sum
+                        // half of the step), the zero terms past C leave the sum as it is
                         nv_fence();
-                        for (int ch = lane; ch < C; ch += 64) scratch_d[ch] = mc.cterm[ch];
+#pragma unroll
+                        for (int w = 0; w < W; ++w) scratch_d[64 * w + lane] = 64 * w + lane < C ? mc.cterm[64 * w + lane] : 0.0;
                         wave_sync();
-                        double r = 0.0;
-                        for (int ch = 0; ch < C; ++ch) r += scratch_d[ch];
+                        const double r = ordered_sum_lds(scratch_d, C);
+                        wave_sync();
                         rss = r / (double)C;
-                        wave_sync();
                     }
                 } else if (want_c || want_r) {
                     int tr_unused;

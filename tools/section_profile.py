@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="env steps per launch (0 = all in one launch)")
     ap.add_argument("--phy", default=None, help="profile the PhyRMSA kernel with this policy (bmfa, sapff, ...) instead")
     ap.add_argument("--defrag", action="store_true")
+    ap.add_argument("--metrics", action="store_true", help="PhyRMSA: per-step number_cuts_total / rss_total_metric outputs")
     args = ap.parse_args()
     sys.path.insert(0, PKG)
     import build as orlg_build   # single-translation-unit build (csrc/orlg_unity.hip, W = 5: NSFNET-320 / US14-268)
@@ -28,6 +29,9 @@ def main():
     from conftest import load_topology
     from optical_rl_gym_amd import BatchedRMSAEnv, _lib
     if args.phy:
+        if args.metrics:
+            import torch
+            torch.zeros(1, device="cuda")   # torch's HIP context first
         from conftest import load_phy_tables
         from optical_rl_gym_amd import BatchedPhyRMSAEnv
         pairs, mod, gsnr = load_phy_tables("us14_k3")
@@ -41,13 +45,20 @@ def main():
         L = _lib.load()
         out = (C.c_ulonglong * 16)()
         L.orlg_debug_sections(out, 1)
-        env.run(args.phy, args.steps, auto_reset=True)
+        if args.metrics:
+            import torch
+            ob = {"number_cuts_total": torch.empty((250, args.batch), dtype=torch.float64, device="cuda"),
+                  "rss_total_metric": torch.empty((250, args.batch), dtype=torch.float64, device="cuda")}
+            for _ in range(args.steps // 250):
+                env.run(args.phy, 250, auto_reset=True, out=ob)
+        else:
+            env.run(args.phy, args.steps, auto_reset=True)
         env.synchronize()
         L.orlg_debug_sections(out, 1)
         tot = sum(out)
         res = {names[i]: round(100.0 * out[i] / tot, 2) for i in range(16) if names[i]}
         res["cycles_per_env_step"] = tot / (args.batch * args.steps)
-        print(json.dumps({"kernel": "phy", "policy": args.phy, "defrag": args.defrag, "percent_of_wave_cycles": res}))
+        print(json.dumps({"kernel": "phy", "policy": args.phy, "defrag": args.defrag, "metrics": args.metrics, "percent_of_wave_cycles": res}))
         return
     env = BatchedRMSAEnv(load_topology("nsfnet_chen_5-paths_6-modulations"), args.batch, num_spectrum_resources=320, load=50,
                          mean_service_holding_time=25, episode_length=1000, seed=10, stats_level=args.stats)
