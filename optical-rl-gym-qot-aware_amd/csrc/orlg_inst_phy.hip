@@ -9,16 +9,24 @@
 #define ORLG_CAT2(a, b) a##b
 #define ORLG_CAT(a, b) ORLG_CAT2(a, b)
 
-// variant bits 0..1 -- 0: the step kernel proper; 1: + periodic defragmentation; 2: + the GN-model admission check;
-// bit 2: the policy sorts channels by the RSS metric (floating point) instead of an integer key
+// variant = extra + 3 * (policy + 1); extra -- 0: the step kernel proper; 1: + periodic defragmentation; 2: + the GN-model
+// admission check; policy = ORLG_PHY_POLICY_* (-1 external actions .. 6)
+#define ORLG_PHY_POL_CASES(base, POL)                                                     \
+    case base: return orlg_phy_kernel<ORLG_INST_W, false, false, POL>;                    \
+    case base + 1: return orlg_phy_kernel<ORLG_INST_W, true, false, POL>;                 \
+    case base + 2: return orlg_phy_kernel<ORLG_INST_W, true, true, POL>;
 orlg_phy_kernel_t ORLG_CAT(orlg_phy_kernel_W, ORLG_INST_W)(int variant) {
     switch (variant) {
-        case 0: return orlg_phy_kernel<ORLG_INST_W, false, false, false>;
-        case 1: return orlg_phy_kernel<ORLG_INST_W, true, false, false>;
-        case 2: return orlg_phy_kernel<ORLG_INST_W, true, true, false>;
-        case 4: return orlg_phy_kernel<ORLG_INST_W, false, false, true>;
-        case 5: return orlg_phy_kernel<ORLG_INST_W, true, false, true>;
-        case 6: return orlg_phy_kernel<ORLG_INST_W, true, true, true>;
+        ORLG_PHY_POL_CASES(0, ORLG_PHY_POLICY_EXTERNAL)
+        ORLG_PHY_POL_CASES(3, ORLG_PHY_POLICY_BMFA_CUT)
+#ifndef ORLG_PHY_FEW_POLICIES   // (instrumented single-unit builds of tools/: external actions and bmfa only)
+        ORLG_PHY_POL_CASES(6, ORLG_PHY_POLICY_BMFA_RSS_METRIC)
+        ORLG_PHY_POL_CASES(9, ORLG_PHY_POLICY_SAPFF)
+        ORLG_PHY_POL_CASES(12, ORLG_PHY_POLICY_BMFF)
+        ORLG_PHY_POL_CASES(15, ORLG_PHY_POLICY_SAPBM)
+        ORLG_PHY_POL_CASES(18, ORLG_PHY_POLICY_FAFF)
+        ORLG_PHY_POL_CASES(21, ORLG_PHY_POLICY_FAFF_RSS)
+#endif
         default: return nullptr;
     }
 }

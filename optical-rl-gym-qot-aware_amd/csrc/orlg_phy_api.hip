@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
 static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation, 2 + GN-model admission check
     const int df = p.gn_on ? 2 : p.defrag_period > 0 ? 1 : 0;
-    const int rssp = (p.mode == ORLG_MODE_STEP && (p.policy == ORLG_PHY_POLICY_BMFA_RSS_METRIC || p.policy == ORLG_PHY_POLICY_FAFF_RSS)) ? 1 : 0;
-    phy_kernel_t k = pick_phy(e->W, df | (rssp << 2));
+    const int pol = p.mode == ORLG_MODE_STEP ? p.policy : ORLG_PHY_POLICY_EXTERNAL;   // one instantiation per policy
+    phy_kernel_t k = pick_phy(e->W, df + 3 * (pol + 1));
     if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
@@ -138,9 +138,8 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
-    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d,%s,%s> grid=%d block=%d lds=%zu", e->W,
-             df == 2 ? "true,true" : df == 1 ? "true,false" : "false,false", rssp ? "true" : "false", nblocks, ORLG_WAVE * wpb,
-             e->lds_block_bytes);
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d,%s,%d> grid=%d block=%d lds=%zu", e->W,
+             df == 2 ? "true,true" : df == 1 ? "true,false" : "false,false", pol, nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 

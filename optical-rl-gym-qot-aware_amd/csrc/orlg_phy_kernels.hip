@@ -1306,8 +1306,14 @@ DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, 
     }
 }
 
-template <int W, bool DF, bool GN, bool RSSP /* the policy sorts channels by the RSS metric (bmfa_rss, faff_rss) */>
+// POL: the policy of the launch (ORLG_PHY_POLICY_*; launches that do not step run the EXTERNAL instantiation).  A compile-time
+// policy turns the per-policy choices inside the channel loops (level as a sort key or not, which metric, first row or best
+// row) into straight-line code: a wave of this kernel is bound by its own instruction latency, and every wave-uniform branch
+// inside an unrolled word loop is a fetch bubble paid W times per candidate path.
+template <int W, bool DF, bool GN, int POL>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_phy_kernel(const OrlgPhyParams p) {
+    // the policy sorts channels by the RSS metric (floating point) instead of an integer key
+    constexpr bool RSSP = POL == ORLG_PHY_POLICY_BMFA_RSS_METRIC || POL == ORLG_PHY_POLICY_FAFF_RSS;
     extern __shared__ __align__(16) unsigned char smem[];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.tables);
@@ -1454,7 +1460,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             uint4 dv[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) dv[w] = make_uint4(0u, 0u, 0u, 0u);
-            if (gnv && (p.policy == ORLG_PHY_POLICY_BMFA_CUT || p.policy == ORLG_PHY_POLICY_FAFF)) {
+            if (gnv && (POL == ORLG_PHY_POLICY_BMFA_CUT || POL == ORLG_PHY_POLICY_FAFF)) {
                 nv_fence();
 #pragma unroll
                 for (int w = 0; w < W; ++w) dv[w] = nv_get(gnv, 64 * w + lane, C);
@@ -1462,7 +1468,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             const int base = tb.pair_base[req_src * N + req_dst];
             const int row = tb.pair_row[req_src * N + req_dst];
             const int demand = tb.bit_rates[req_br];
-            const int policy = p.policy;
+            constexpr int policy = POL;
             int a_path = -2, nsel = 0;
             // requested now, used after the virtual-layer check as well: the modulation levels of the lane's channels on the K
             // candidate paths (one or two words per channel) and the paths' node records (lane 2 i, 2 i + 1: path i)

@@ -22,7 +22,7 @@ def main():
     args = ap.parse_args()
     sys.path.insert(0, PKG)
     import build as orlg_build   # single-translation-unit build (csrc/orlg_unity.hip, W = 5: NSFNET-320 / US14-268)
-    orlg_build.build_unity(LIB, ["-DORLG_SECTIONS"], w=5, verbose=False)
+    orlg_build.build_unity(LIB, ["-DORLG_SECTIONS", "-DORLG_PHY_FEW_POLICIES"], w=5, verbose=False)
     os.environ["ORLG_LIB_PATH"] = LIB
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
