@@ -1288,8 +1288,8 @@ DEV uint32_t rec_store(OrlgPhySvc *dst, const double *arrival_lds, uint32_t seq,
     return v;
 }
 // first service due at `time` among the near buffer's entries (earliest release, ties: lowest queue index)
-DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, int &vpos) {
-    double best_t = 0.0;
+DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, int &vpos, double &best_t) {
+    best_t = 0.0;
     victim = -1; vpos = -1;
     for (int c0 = 0; c0 < nb.n; c0 += 64) {
         const int c = c0 + lane;
@@ -1428,17 +1428,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     ReleaseAhead ra;
     ra.q = -1; ra.rec = 0u; ra.key = 0; ra.cs_ok = false; ra.cs_e = 0u; ra.cs_n = 0; ra.last = -1; ra.lrec = 0u; ra.cvl = 0u;
     // the next ring entry, requested one step ahead: lanes 0, 1 inter-arrival time, lanes 2, 3 holding time, lane 4 the request
+    // (lanes 8, 9: the inter-arrival time of the entry after it, for the look-ahead of the release loop)
     uint32_t pf_ring = 0u;
-    bool pf_ring_ok = false;
+    bool pf_ring_ok = false, pf_next_ok = false;
     auto ring_fetch = [&]() {
         pf_ring_ok = ring_cnt > 0;
+        pf_next_ok = ring_cnt > 1;
         if (pf_ring_ok) {
             const OrlgPhyParams __attribute__((address_space(4))) *kq =
                 (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
             const size_t ro = (size_t)env * ORLG_RING + ring_pos;
             const uint32_t *src = lane < 2 ? reinterpret_cast<const uint32_t *>(kq->ring_iat + ro) + lane
-                                : lane < 4 ? reinterpret_cast<const uint32_t *>(kq->ring_ht + ro) + (lane - 2) : kq->ring_req + ro;
-            if (lane < 5) pf_ring = *src;
+                                : lane < 4 ? reinterpret_cast<const uint32_t *>(kq->ring_ht + ro) + (lane - 2)
+                                : lane < 8 ? kq->ring_req + ro : reinterpret_cast<const uint32_t *>(kq->ring_iat + ro + 1) + (lane - 8);
+            if (lane < 5 || (pf_next_ok && (lane == 8 || lane == 9))) pf_ring = *src;
         }
     };
     if (p.mode == ORLG_MODE_STEP) ring_fetch();
@@ -1446,15 +1449,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy: virtual layer
         if (p.mode == ORLG_MODE_STEP) {
-            // the release the next arrival will trigger first, looked up now (ReleaseAhead): its record is on its way while the
-            // policy runs
-            ra.q = -1; ra.cs_ok = false; ra.last = -1;
-            if (pf_ring_ok && current_time <= nb.horizon) {
-                const double next_time = current_time + __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 1), __builtin_amdgcn_readlane((int)pf_ring, 0));
-                int vq, vp;
-                nb_first_due(nb, next_time, lane, vq, vp);
-                if (vq >= 0) { ra.q = vq; ra.rec = rec_dword(grec, vq, lane); }
-            }
+            // (ra.q: the service the next arrival will release first, looked up by the release loop of the previous step)
+            ra.cs_ok = false; ra.last = -1;
             // D of the lane's channels (cut metric): requested first, used after the virtual-layer check; it serves every candidate
             // path of the request.  (The fence: entries other lanes rewrote since the last look -- their stores are long done.)
             uint4 dv[W];
@@ -1967,6 +1963,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             wave_sync();
         }
 
+        bool defrag_now = false;   // this step ends with a defragmentation cycle (services_processed % defrag_period == 0)
         SEC(7);  // next arrival
         // ============================================================== _next_service (phy_rmsa_env.py:969-1017)
         if (p.mode != ORLG_MODE_EPISODE_RESET && !new_service) {
@@ -2010,6 +2007,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             const double r_iat = __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 1), __builtin_amdgcn_readlane((int)pf_ring, 0));
             const double ht = __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 3), __builtin_amdgcn_readlane((int)pf_ring, 2));
             const uint32_t rq = (uint32_t)__builtin_amdgcn_readlane((int)pf_ring, 4);
+            const bool have_next = pf_next_ok;
+            const double next_iat = __hiloint2double(__builtin_amdgcn_readlane((int)pf_ring, 9), __builtin_amdgcn_readlane((int)pf_ring, 8));
             ring_pos += 1; ring_cnt -= 1;
             if (p.mode == ORLG_MODE_STEP) ring_fetch();   // the entry of the next step
             else pf_ring_ok = false;
@@ -2032,9 +2031,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             if (current_time > nb.horizon) {
                 if (!nb_rebuild(nb, gq, n_running, current_time, p.holding_lambda, lane) && lane == 0) ws->q_overflow |= 8;
             }
+            // the scan looks one arrival ahead: the earliest release up to the NEXT arrival's time is this step's victim when it
+            // is due now, and otherwise the service the next step will release first -- its record is requested right away
+            // (ReleaseAhead; a defragmentation cycle in between drops the look-ahead)
+            const double look_time = have_next ? current_time + next_iat : current_time;
+            int ahead_q = -1;
             for (;;) {
                 int victim, vpos;
-                nb_first_due(nb, current_time, lane, victim, vpos);
+                double vt;
+                nb_first_due(nb, look_time, lane, victim, vpos, vt);
+                if (victim >= 0 && vt > current_time) { ahead_q = victim; victim = -1; }
                 if (victim < 0) break;
                 SEC(10);  // release apply
                 const bool ahead = victim == ra.q;   // the service looked up at the start of the step: its data is here
@@ -2141,14 +2147,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 wave_sync();
                 ra.q = -1; ra.last = -1;   // the queue has changed: what was looked up ahead is stale
             }
+            ra.q = -1;
+            if (DF && p.mode == ORLG_MODE_STEP && p.defrag_period > 0) defrag_now = uni((int)(ws->c[0] % p.defrag_period)) == 0;
+            if (ahead_q >= 0 && !defrag_now && p.mode == ORLG_MODE_STEP) { ra.q = ahead_q; ra.rec = rec_dword(grec, ahead_q, lane); }
         }
 
         if (DF && p.mode == ORLG_MODE_STEP && p.defrag_period > 0) {
         SEC(11);  // defragmentation
             // periodic defragmentation (phy_rmsa_env.py:355-417): services_processed % defrag_period == 0
             wave_sync();
-            const long long processed = ws->c[0];
-            if (processed % p.defrag_period == 0)
+            if (defrag_now)
                 phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv, mc SEC_ARGS);
         }
 
