@@ -709,6 +709,7 @@ struct MetricCache {
     bool on, want_rss;
     int total_runs;
     double *cterm;          // HBM [cpad]
+    double __attribute__((address_space(3))) *lterm;   // the same terms in LDS (mc_after<true>)
     const double *sqrt_tab;
     int E, W;
 };
@@ -721,13 +722,18 @@ DEV void mc_before(const u64 *occ, MetricCache &mc, int ch, int lane) {
     const uint32_t col = mc_column(occ, mc, ch, lane);
     mc.total_runs -= __builtin_popcount(col & ~(col << 1));
 }
+// LT: the terms live in the wave's LDS (lterm) instead of the HBM scratch array -- the kernels whose steps leave the per-channel
+// LDS scratch alone (no RSS-metric policy, no defragmentation): no HBM round trip per step for the channel-order sum
+template <bool LT = false>
 DEV void mc_after(const u64 *occ, MetricCache &mc, int ch, int lane) {
     if (!mc.on) return;
     const uint32_t col = mc_column(occ, mc, ch, lane);
     mc.total_runs += __builtin_popcount(col & ~(col << 1));
     if (mc.want_rss) {
         const double t = rss_of_column(col, mc.sqrt_tab);
-        if (lane == 0) mc.cterm[ch] = t;
+        if (lane == 0) {
+            if (LT) mc.lterm[ch] = t; else mc.cterm[ch] = t;
+        }
     }
 }
 
@@ -1415,11 +1421,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     mc.want_rss = (p.out_mask & (1 << ORLG_PHY_OUT_RSS)) != 0;
     mc.total_runs = 0;
     mc.cterm = p.cterm ? p.cterm + (size_t)env * p.cpad : nullptr;
+    mc.lterm = (double __attribute__((address_space(3))) *)scratch_d;
+    constexpr bool LT = !RSSP && !DF;   // the steps of this instantiation never touch scratch_d: the RSS terms stay there
     mc.sqrt_tab = tb.sqrt_tab; mc.E = E; mc.W = W;
     if (mc.on) {
         double c0_unused, r0_unused;
         phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, true, mc.want_rss, true, c0_unused, r0_unused, mc.total_runs);
-        if (mc.want_rss) {
+        if (mc.want_rss && !LT) {
             for (int ch = lane; ch < C; ch += 64) mc.cterm[ch] = scratch_d[ch];
             wave_sync();
         }
@@ -1827,7 +1835,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                     if (mc.on) {
                         wave_sync();
-                        for (int ci = 0; ci < nsel; ++ci) mc_after(occ, mc, sel_ch[ci], lane);
+                        for (int ci = 0; ci < nsel; ++ci) mc_after<LT>(occ, mc, sel_ch[ci], lane);
                     }
                     if (gnv) {   // the nodes of the path lose free links on these channels
                         uint4 cv;
@@ -1914,9 +1922,11 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                         // reference's channel-order float64 sum: 8 terms per LDS round trip (one trip per term made this sum
                         // half of the step), the zero terms past C leave the sum as it is
                         nv_fence();
+                        if (!LT) {
 #pragma unroll
-                        for (int w = 0; w < W; ++w) scratch_d[64 * w + lane] = 64 * w + lane < C ? mc.cterm[64 * w + lane] : 0.0;
-                        wave_sync();
+                            for (int w = 0; w < W; ++w) scratch_d[64 * w + lane] = 64 * w + lane < C ? mc.cterm[64 * w + lane] : 0.0;
+                            wave_sync();
+                        }
                         const double r = ordered_sum_lds(scratch_d, C);
                         wave_sync();
                         rss = r / (double)C;
@@ -2118,7 +2128,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     wave_sync();
 #pragma unroll
                     for (int w = 0; w < W; ++w)
-                        for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_after(occ, mc, 64 * w + ctz64(m), lane);
+                        for (u64 m = readlane64(freemask[w], 0); m; m &= m - 1) mc_after<LT>(occ, mc, 64 * w + ctz64(m), lane);
                 }
                 if (gnv) {   // the returned channels: lane = channel of word w, the nodes of the path gain free links
                     uint4 cv_rel;
