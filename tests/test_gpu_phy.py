@@ -279,7 +279,42 @@ def test_phy_five_paths_synthetic_tables(policy, device_log_in_oracle):
     env.close()
 
 
-@pytest.mark.parametrize("policy,launch_power_dbm", [("bmfa", 0.0), ("sapff", 2.0)])
+@pytest.mark.parametrize("defrag", [None, "cut", "rss"])
+@pytest.mark.parametrize("policy", ["bmfa", "bmfa_rss", "sapff", "bmff", "sapbm", "faff", "faff_rss"])
+def test_phy_every_policy_instantiation_vs_oracle(policy, defrag, device_log_in_oracle):
+    """The step kernel is instantiated per policy (x plain / + defragmentation): every one of them against the oracle on US14
+    with the shipped tables, per-step metrics written, several launches (the node-degree vectors and the cached RSS terms are
+    rebuilt at every launch start)."""
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    kw = dict(load=1200, mean_service_holding_time=25, episode_length=150, seed=21, grooming=policy in ("bmfa", "bmfa_rss"))
+    if defrag:
+        kw.update(defrag_period=7, number_moves=6, metric=defrag)
+    env = make_env(topo, tables, kw, 3)
+    outs = ("act_path", "channels", "channels_used", "accepted", "number_cuts_total", "rss_total_metric", "defrag_counters")
+    parts = [env.run(policy, n, outputs=outs, auto_reset=True) for n in (130, 1, 200, 69)]
+    tr = {k: np.concatenate([q[k] for q in parts]) for k in outs}
+    pol_index = {"bmfa": 0, "bmfa_rss": 1, "sapff": 2, "bmff": 3, "sapbm": 4, "faff": 5, "faff_rss": 6}[policy]
+    assert env.last_kernel().startswith("orlg_phy_kernel<5,%s,%d>" % ("true,false" if defrag else "false,false", pol_index)), env.last_kernel()
+    av, cnt = env.available_channels(), env.counters()
+    assert env.episode_stats()["queue_overflow"].max() == 0
+    for i in range(3):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=21 + i)
+        ot = o.run(policy, 400, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["channels_used"][:, i, :12].astype(np.float64), ot["ch_used"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        assert np.array_equal(tr["rss_total_metric"][:, i], ot["rss_total_metric"]), i
+        assert np.array_equal(tr["defrag_counters"][:, i, 1], ot["num_moves_groom"]), i
+        assert np.array_equal(av[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        assert env.channel_state(i) == o.channel_state(), i
+        o.close()
+    env.close()
+
+
+@pytest.mark.parametrize("policy,launch_power_dbm", [("bmfa", 0.0), ("sapff", 2.0), ("faff", 1.0), ("bmff", 0.0), ("bmfa_rss", 1.0),
+                                                     ("sapbm", 0.0), ("faff_rss", 2.0)])
 def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_oracle):
     """GN-model admission check of the chosen channels inside the QoT-aware step (include/orlg.h orlg_gn_gate).  The reference
     gates by table only: this mode is PARITY UNPINNED by it and pinned to the oracle, which feeds its restatement of
