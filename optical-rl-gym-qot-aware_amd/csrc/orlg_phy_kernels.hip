@@ -464,7 +464,8 @@ template <int W>
 DEV void phy_row_keys(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, u64 acc, int idp, int gid, const uint8_t *mrow,
                       int lane, int metric_mode /* 0 cut, 2 none */, bool flat_level, int (&key)[W],
                       const uint4 (&dv)[W] /* D of the lane's channels (cut metric with node-degree vectors) */,
-                      const uint32_t (&lvk)[2 * W] /* levels of the lane's channels on all paths (mod_k) */,
+                      const uint32_t (&lvk)[W] /* levels of the lane's channels on paths 0..3 (mod_k) */,
+                      const uint32_t *mk_hi /* mod_k row of the lane's first channel, second word: paths 4.. */,
                       const uint4 &nvq /* lane 2 i, 2 i + 1: node record of candidate path i */) {
     // key = (level << 20) + (metric << 9) + kc, kc = (1024 << 9) | (511 - channel); bits of channels >= C are never set in the
     // occupancy (valid_mask), so "free on the path" (the lane's bit of the path's word) is the whole condition
@@ -489,7 +490,7 @@ DEV void phy_row_keys(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, 
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             int s = nv_dot(nr.c, dv[w]) - chs[w];
-            const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[2 * w] : lvk[2 * w + 1]) >> lsh) & 0xffu);
+            const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[w] : mk_hi[128 * w]) >> lsh) & 0xffu);
             const int kk = (lvl << 20) + (kpath - 64 * w) - (s << 10);
             key[w] = select_by_lane_mask(readlane64(acc, idp * W + w), kk, -1);
         }
@@ -518,7 +519,7 @@ DEV void phy_row_keys(const u64 *occ, const PhyTab &tb, const OrlgPhyParams &p, 
     }
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-        const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[2 * w] : lvk[2 * w + 1]) >> lsh) & 0xffu);
+        const int lvl = flat_level ? 0 : (int)(((idp < 4 ? lvk[w] : mk_hi[128 * w]) >> lsh) & 0xffu);
         const int kk = (lvl << 20) + (m[w] << 9) + (kc0 - 64 * w);
         key[w] = select_by_lane_mask(readlane64(acc, idp * W + w), kk, -1);
     }
@@ -1259,23 +1260,17 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
 // DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
 // without it run the other one, whose registers are not shared with code they never execute
 // GN: ... and the one that also carries the GN-model admission check (orlg_gn_gate)
-// ---- the release of the NEXT step, looked up ahead.  The arrival times come from the pre-generated ring, so at the start of a
-// step the wave already knows the time of the following arrival and can look for the service that will be released first then;
-// its record (and, once that has arrived, its channel_state list and the queue's last record, which will take its place) are
-// requested long before the release needs them.  The release loop still finds its victims by itself: the prefetched data is
-// used only when the loop's first victim is the one looked up (anything else falls back to plain loads).
+// ---- the release of the NEXT step, looked up ahead.  The arrival times come from the pre-generated ring, so the release
+// loop's scan already knows the time of the following arrival and finds the service that will be released first then; its
+// record is requested right away and is on lanes when the next step's release loop needs it.  That loop still finds its
+// victims by itself: the record is used only when its first victim is the one looked up (anything else is a plain load).
+// (Requesting the service's channel_state list, node weights and the queue's last record ahead as well was measured: no
+// gain, four more registers held across the step.)
 typedef int orlg_v4i __attribute__((ext_vector_type(4)));
 #define ORLG_GPTR(T, v) ((T __attribute__((address_space(1))) *)(v))   // an output array: global memory, not a generic pointer
 struct ReleaseAhead {
     int q;            // queue index of the looked-up service, -1: none
     uint32_t rec;     // lane < 12: dword `lane` of its record
-    int key;          // its channel_state list (valid when cs_ok)
-    bool cs_ok;       // the list below was requested (the service holds partially used channels)
-    uint32_t cs_e;    // lane i: entry i
-    int cs_n;         // list length (as loaded: a byte on every lane)
-    uint32_t cvl;     // lane < 4: dword `lane` of its path's node weights (cut metric with node-degree vectors)
-    int last;         // queue index of the last record when `lrec` was requested, -1: none
-    uint32_t lrec;    // lane < 12: dword `lane` of the last record; lanes 12, 13: its release time
 };
 DEV uint32_t rec_dword(const OrlgPhySvc *grec, int q, int lane) {
     return lane < 12 ? reinterpret_cast<const uint32_t *>(grec + q)[lane] : 0u;
@@ -1434,7 +1429,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     }
 
     ReleaseAhead ra;
-    ra.q = -1; ra.rec = 0u; ra.key = 0; ra.cs_ok = false; ra.cs_e = 0u; ra.cs_n = 0; ra.last = -1; ra.lrec = 0u; ra.cvl = 0u;
+    ra.q = -1; ra.rec = 0u;
     // the next ring entry, requested one step ahead: lanes 0, 1 inter-arrival time, lanes 2, 3 holding time, lane 4 the request
     // (lanes 8, 9: the inter-arrival time of the entry after it, for the look-ahead of the release loop)
     uint32_t pf_ring = 0u;
@@ -1457,8 +1452,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy: virtual layer
         if (p.mode == ORLG_MODE_STEP) {
-            // (ra.q: the service the next arrival will release first, looked up by the release loop of the previous step)
-            ra.cs_ok = false; ra.last = -1;
             // D of the lane's channels (cut metric): requested first, used after the virtual-layer check; it serves every candidate
             // path of the request.  (The fence: entries other lanes rewrote since the last look -- their stores are long done.)
             uint4 dv[W];
@@ -1476,17 +1469,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             int a_path = -2, nsel = 0;
             // requested now, used after the virtual-layer check as well: the modulation levels of the lane's channels on the K
             // candidate paths (one or two words per channel) and the paths' node records (lane 2 i, 2 i + 1: path i)
-            uint32_t lvk[2 * W];
+            uint32_t lvk[W];   // (a fifth path's levels are read where they are needed: K = 5 pays a wait, K <= 4 no registers)
             uint4 nvq = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-            for (int w = 0; w < 2 * W; ++w) lvk[w] = 0u;
+            for (int w = 0; w < W; ++w) lvk[w] = 0u;
+            const uint32_t *mk_hi = p.mod_k + ((size_t)row * p.cpad + lane) * 2 + 1;
             if (!RSSP && policy != ORLG_PHY_POLICY_EXTERNAL) {
                 const uint32_t *mk = p.mod_k + ((size_t)row * p.cpad + lane) * 2;
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    lvk[2 * w] = mk[128 * w];
-                    if (K > 4) lvk[2 * w + 1] = mk[128 * w + 1];
-                }
+                for (int w = 0; w < W; ++w) lvk[w] = mk[128 * w];
                 if (gnv && lane < 2 * K) nvq = p.nvrec[2 * base + lane];
             }
 
@@ -1561,7 +1552,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             head_key[idp] = -1;
                             if (idp < K) {
                                 int key[W];
-                                phy_row_keys<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, key, dv, lvk, nvq);
+                                phy_row_keys<W>(occ, tb, p, acc, idp, base + idp, p.mod_t + (size_t)(row * K + idp) * p.cpad, lane, metric_mode, flat, key, dv, lvk, mk_hi, nvq);
                                 const int h = phy_keys_best<W>(key);
                                 if (h >= 0) {
                                     head_key[idp] = h; alive |= 1u << idp;
@@ -1590,7 +1581,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                                 for (int w = 0; w < W; ++w) key[w] = keep_key[w];
                                 keep_idp = -1;
                             } else {
-                                phy_row_keys<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, key, dv, lvk, nvq);
+                                phy_row_keys<W>(occ, tb, p, acc, best, base + best, mrow, lane, metric_mode, flat, key, dv, lvk, mk_hi, nvq);
                             }
                             int unassigned = demand;
                             nsel = 0;
@@ -1697,31 +1688,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
             }
 
             SEC(5);  // provision
-            // the looked-up release, second stage: its record has arrived by now (the policy waited for loads requested earlier);
-            // its channel_state list (only if it shares channels), its path's node weights and the queue's last record, which
-            // will move into its place, are requested BEFORE this step's stores go out -- a wait for a load also waits for every
-            // store issued before it
-            int prov_key = -1;   // channel_state list this step's provisioning rewrites
-            if (ra.q >= 0) {
-                const uint32_t d3 = (uint32_t)__builtin_amdgcn_readlane((int)ra.rec, 3);
-                const int rgid = (int)(d3 & 0xffffu), rnch = (int)((d3 >> 16) & 0xffu), rflags = (int)(d3 >> 24);
-                // channel i: dword 4 + i / 2, half i & 1; partial = bit 14
-                const bool lane_ch = lane >= 4 && lane < 4 + ((rnch + 1) >> 1);
-                const uint32_t pm = (2 * (lane - 4) + 1 < rnch) ? 0x40004000u : 0x00004000u;
-                if (ballot(lane_ch && (ra.rec & pm) != 0u) != 0ull) {
-                    ra.key = svc_key(tb, N, K, rgid, rflags);
-                    ra.cs_ok = true;
-                    ra.cs_n = (int)gcs_n[ra.key];
-                    ra.cs_e = lane < p.cs_len ? gcs[(size_t)ra.key * p.cs_len + lane] : 0u;
-                }
-                if (gnv && lane < 4) ra.cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * rgid)[lane];
-                if (n_running >= 2 && ra.q != n_running - 1) {
-                    ra.last = n_running - 1;
-                    ra.lrec = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + ra.last)[lane]
-                                        : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + ra.last)[lane - 12] : 0u;
-                }
-            }
-            // ========================================================== PhyRMSAEnv.step (phy_rmsa_env.py:272-351)
             bool accepted = false;
             double gn_last = __longlong_as_double(0x7ff8000000000000ll);   // NaN: no GN check in this step
             const bool dirbit = req_src > req_dst;
@@ -1742,20 +1708,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
                 if (ok) {
                     cs_store(gcs, gcs_n, key, l, lane);
-                    prov_key = key;
                     if (lane == 0) { ws->c[1] += 1; ws->c[3] += 1; ws->c[5] += demand; ws->c[7] += demand; }
                     accepted = true;
                     if (n_running < Q) {
                         if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
-                        const uint32_t newrec = rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, 1 | (dirbit ? 2 : 0),
+                        rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, 1 | (dirbit ? 2 : 0),
                                   lane < nsel ? (uint32_t)(sel_ch[lane] | (sel_used[lane] << 9) | (1 << 14)) : 0xffffu, lane);
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
-                            if (ra.q >= 0) {   // the new record is the queue's last one now
-                                ra.last = qidx;
-                                ra.lrec = lane < 12 ? newrec : lane == 12 ? (uint32_t)__double2loint(rel) : (uint32_t)__double2hiint(rel);
-                            }
                             n_running += 1;
                             if (rel <= nb.horizon) {
                                 if (nb.n < ORLG_PHY_NB) {
@@ -1872,22 +1833,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                             }
                         }
                         cs_store(gcs, gcs_n, cs_key_p, csl, lane);
-                        prov_key = cs_key_p;
                         if (overflow && lane == 0) ws->q_overflow |= 4;
                     }
                     accepted = true;
                     // _add_release: compact queue, append at n_running
                     if (n_running < Q) {
                         if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
-                        const uint32_t newrec = rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, dirbit ? 2 : 0,
+                        rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, dirbit ? 2 : 0,
                                   lane < nsel ? (uint32_t)(my_ch | (my_used << 9) | ((my_used != my_cap ? 1 : 0) << 14)) : 0xffffu, lane);
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
-                            if (ra.q >= 0) {   // the new record is the queue's last one now
-                                ra.last = qidx;
-                                ra.lrec = lane < 12 ? newrec : lane == 12 ? (uint32_t)__double2loint(rel) : (uint32_t)__double2hiint(rel);
-                            }
                             n_running += 1;
                             if (rel <= nb.horizon) {
                                 if (nb.n < ORLG_PHY_NB) {
@@ -1907,7 +1863,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
             }
 
-            if (ra.cs_ok && ra.key == prov_key) ra.cs_ok = false;   // this step rewrote the list that was requested ahead
             SEC(6);  // outputs
             // per-step outputs
             if (p.out_mask) {
@@ -2082,21 +2037,16 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
                 // every load of this release first (what was not requested ahead), every store last
                 const bool move_last = victim != n_running - 1;
-                const bool last_ahead = ahead && ra.last == n_running - 1;
-                uint32_t lastv = ra.lrec;
-                if (move_last && !last_ahead)
+                uint32_t lastv = 0u;   // the queue's last record (lanes 0..11) and release time (12, 13): it takes the victim's place
+                if (move_last)
                     lastv = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + (n_running - 1))[lane]
                                       : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + (n_running - 1))[lane - 12] : 0u;
-                uint32_t cvl = ra.cvl;
-                if (gnv && !ahead && lane < 4) cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * sv_gid)[lane];
+                uint32_t cvl = 0u;
+                if (gnv && lane < 4) cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * sv_gid)[lane];
                 CsList l;
                 l.e = 0u; l.n = 0; l.cap = p.cs_len;
                 if (any_partial) {
-                    if (ahead && ra.cs_ok && ra.key == key) {
-                        l.n = uni(ra.cs_n); l.e = lane < l.n ? ra.cs_e : 0u;
-                    } else {
-                        l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
-                    }
+                    l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
                     for (int ci = 0; ci < sv_nch; ++ci) {
                         const int raw = __builtin_amdgcn_readlane(raw_l, ci);
                         if (!(raw & (1 << 14))) continue;
@@ -2155,7 +2105,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 nb.n -= 1;
                 if (vpos != nb.n && lane == 0) { nb.t[vpos] = nb.t[nb.n]; nb.qi[vpos] = nb.qi[nb.n]; }
                 wave_sync();
-                ra.q = -1; ra.last = -1;   // the queue has changed: what was looked up ahead is stale
+                ra.q = -1;   // the queue has changed: what was looked up ahead is stale
             }
             ra.q = -1;
             if (DF && p.mode == ORLG_MODE_STEP && p.defrag_period > 0) defrag_now = uni((int)(ws->c[0] % p.defrag_period)) == 0;
