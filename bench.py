@@ -138,7 +138,9 @@ def roofline_block(key, kernel, kernel_ms, A, env_steps_per_launch, batch):
           "traffic": None, "traffic_unit": "bytes per launch", "kernel": kernel, "kernel_ms_per_launch": kernel_ms,
           "algorithmic_bytes_per_env_step": A, "env_steps_per_launch": env_steps_per_launch,
           "note": "bound/achieved/frac follow SURVEY 8(d)'s algorithmic-byte accounting; the state lives in LDS for a whole "
-                  "launch, so measured HBM traffic is far below it and the binding resource is VALU issue (valu_issue block)"}
+                  "launch, so measured HBM traffic is far below it; what binds: VALU issue for the RMSA step kernels (valu_issue "
+                  "block: 83-99 % busy), the wave's own instruction latency for the QoT-aware step (valu_busy ~0.63: DESIGN 2.9), "
+                  "the state's HBM round trip for one-step launches (hbm_measured_GBps)"}
     pmc = load_pmc(key)
     if pmc and pmc.get("batch") == batch:
         per = pmc["per_env_step"]
