@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--stats", default="full", choices=["full", "network", "counters"])
     ap.add_argument("--policy", default="sap_ff")
     ap.add_argument("--step-kernel", default="auto", choices=["auto", "wave", "group"])
+    ap.add_argument("--queue-capacity", type=int, default=0, help="release-queue slots per environment (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
     ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "deeprmsa"],
@@ -194,7 +195,7 @@ def rmsa_record(clock, topo_name, B, chunk, warm, steps, args, rank, local_rank,
     from optical_rl_gym_amd.distributed import shard_base_seed
     topo = load_topology(topo_name)
     env = BatchedRMSAEnv(topo, B, **ENV_KW, seed=shard_base_seed(10, B, rank), stats_level=args.stats, device=local_rank,
-                         step_kernel=args.step_kernel)
+                         step_kernel=args.step_kernel, queue_capacity=args.queue_capacity)
     env.set_stream(clock.stream.cuda_stream)
     launch = lambda: env.run(args.policy, chunk, auto_reset=True)
     for _ in range(max(1, warm)):

@@ -64,7 +64,8 @@ typedef struct orlg_rmsa_config {
     int32_t num_bit_rates;    /* 1..64 */
     int32_t j;                /* DeepRMSA: blocks per path in action / observation (deeprmsa_env.py:34) */
     int32_t reward_mode;      /* 0: 1/0 (optical_network_env.py:213-214); 1: +1/-1 (deeprmsa_env.py:123-124) */
-    int32_t queue_capacity;   /* release-queue slots per env, multiple of 64; 0 = pick from the load */
+    int32_t queue_capacity;   /* release-queue slots per env (rounded up to a multiple of 16, at least 64); 0 = pick from the
+                               * load: mean + 10 sigma of the M/M/inf occupancy */
     int32_t stats_level;      /* ORLG_STATS_* */
     int32_t step_kernel;      /* ORLG_KERNEL_*: which step kernel serves the first-fit policies and external actions */
     double arrival_lambda;    /* 1 / mean_service_inter_arrival_time (rmsa_env.py:646-648) */

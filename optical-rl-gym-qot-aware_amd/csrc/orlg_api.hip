@@ -468,7 +468,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         double load = c->arrival_lambda / c->holding_lambda;
         Q = (int)(load + 10.0 * std::sqrt(load));
     }
-    Q = ((Q + 63) / 64) * 64;
+    Q = ((Q + 15) / 16) * 16;   // 16 slots = one row of the four-environments-per-wave kernel, 128 bytes of times
     if (Q < 64) Q = 64;
     if (Q > 4096) { orlg_destroy(e); return fail(ORLG_ERR_INVALID, "queue_capacity %d too large for LDS (max 4096)", Q); }
     p.Q = Q;
