@@ -198,10 +198,16 @@ DEV double rss_of_column(uint32_t col, const double *sqrt_tab) {
 DEV double ordered_sum_lds(const double *terms, int n) {
     double r = 0.0;
     const double2 *sd2 = reinterpret_cast<const double2 *>(terms);
-    for (int c8 = 0; c8 < (n + 7) / 8; ++c8) {
-        const double2 a0 = sd2[4 * c8], a1 = sd2[4 * c8 + 1], a2 = sd2[4 * c8 + 2], a3 = sd2[4 * c8 + 3];
+    const int n8 = (n + 7) / 8;
+    // the next eight terms are requested before the current eight are added: the additions (dependent, ~8 cycles each) hide
+    // the round trip
+    double2 a0 = sd2[0], a1 = sd2[1], a2 = sd2[2], a3 = sd2[3];
+    for (int c8 = 1; c8 < n8; ++c8) {
+        const double2 b0 = sd2[4 * c8], b1 = sd2[4 * c8 + 1], b2 = sd2[4 * c8 + 2], b3 = sd2[4 * c8 + 3];
         r += a0.x; r += a0.y; r += a1.x; r += a1.y; r += a2.x; r += a2.y; r += a3.x; r += a3.y;
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
     }
+    r += a0.x; r += a0.y; r += a1.x; r += a1.y; r += a2.x; r += a2.y; r += a3.x; r += a3.y;
     return r;
 }
 // _calculate_total_cuts (phy_rmsa_env.py:1195-1203) and calculate_total_r_spatial (:1110-1121): run-length statistics of
