@@ -163,7 +163,8 @@ DEV void copy_words(void *dst, const void *src, int bytes, int lane) {
 // Regenerate all 624 words in place (CPython _randommodule.c genrand_uint32).  Sub-round r handles
 // kk = 64r + lane; mt[kk+1] is still old (same or later sub-round), mt[kk+397] is old for kk < 227 and
 // mt[kk-227] is already new for kk >= 227, exactly as in the sequential loop.
-DEV void mt_regenerate(uint32_t *mt, int lane) {
+template <typename MT /* pointer to the 624 state words: generic or LDS-qualified */>
+DEV void mt_regenerate(MT mt, int lane) {
     for (int r = 0; r < 10; ++r) {
         int kk = 64 * r + lane;
         uint32_t v = 0;
@@ -217,12 +218,20 @@ DEV int choice_cum(const double *cum, int n, double u, int lane) {
 // on the network state, so lane j produces request j of the RNG stream: words [idx + 10 j, idx + 10 j + 10).  At most
 // one MT19937 regeneration happens inside a refill (n is capped accordingly), exactly where the sequential
 // generator would do it.  Returns the number of requests written to the ring.
-__device__ __noinline__ int refill_requests(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req,
-                                            const double *src_cum, const double *dst_cum, const double *br_cum, int *idx_io,
-                                            int N, int NBR, double lam_arrival, double lam_holding) {
+// (Out of line, so its pointers carry their address space in the signature: through generic pointers every access of the
+// MT19937 state and the tables in LDS was a flat instruction.  RING_LDS: the ring lives in LDS (wave-per-environment kernel)
+// or in HBM (the other two).  Returns count | new index << 8.)
+typedef __attribute__((address_space(3))) uint32_t orlg_lds_u32;
+typedef __attribute__((address_space(3))) double orlg_lds_f64;
+typedef __attribute__((address_space(3))) const double orlg_lds_cf64;
+typedef __attribute__((address_space(1))) uint32_t orlg_glb_u32;
+typedef __attribute__((address_space(1))) double orlg_glb_f64;
+template <bool RING_LDS>
+__device__ __noinline__ int refill_requests_as(orlg_lds_u32 *mt, void *ring_iat_v, void *ring_ht_v, void *ring_req_v,
+                                               orlg_lds_cf64 *src_cum, orlg_lds_cf64 *dst_cum, orlg_lds_cf64 *br_cum, int idx,
+                                               int N, int NBR, double lam_arrival, double lam_holding) {
     // out of line on purpose: it runs once per ~62 steps and must not add register pressure to the step loop
     const int lane = threadIdx.x & 63;
-    int idx = *idx_io;
     const double ylam_arrival = recip_refine(lam_arrival), ylam_holding = recip_refine(lam_holding);
     int n = (2 * ORLG_MT_N - idx) / 10;
     n = n > ORLG_RING ? ORLG_RING : n;
@@ -256,7 +265,7 @@ __device__ __noinline__ int refill_requests(uint32_t *mt, double *ring_iat, doub
         for (int i = 0; i < N - 1; ++i) src += src_cum[i] <= x ? 1 : 0;
     }
     {
-        const double *row = dst_cum + src * N;
+        orlg_lds_cf64 *row = dst_cum + src * N;
         const double x = u[3] * (row[N - 1] + 0.0);
         for (int i = 0; i < N - 1; ++i) dst += row[i] <= x ? 1 : 0;
     }
@@ -265,12 +274,31 @@ __device__ __noinline__ int refill_requests(uint32_t *mt, double *ring_iat, doub
         for (int i = 0; i < NBR - 1; ++i) bri += br_cum[i] <= x ? 1 : 0;
     }
     // entries past n are dead; they are zeroed so that a snapshot of the state does not depend on what the ring held before
-    ring_iat[lane] = lane < n ? iat : 0.0;
-    ring_ht[lane] = lane < n ? ht : 0.0;
-    ring_req[lane] = lane < n ? ((uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)bri << 16)) : 0u;
+    const double o_iat = lane < n ? iat : 0.0, o_ht = lane < n ? ht : 0.0;
+    const uint32_t o_rq = lane < n ? ((uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)bri << 16)) : 0u;
+    if (RING_LDS) {
+        ((orlg_lds_f64 *)ring_iat_v)[lane] = o_iat; ((orlg_lds_f64 *)ring_ht_v)[lane] = o_ht; ((orlg_lds_u32 *)ring_req_v)[lane] = o_rq;
+    } else {
+        ((orlg_glb_f64 *)ring_iat_v)[lane] = o_iat; ((orlg_glb_f64 *)ring_ht_v)[lane] = o_ht; ((orlg_glb_u32 *)ring_req_v)[lane] = o_rq;
+    }
     wave_sync();
-    *idx_io = idx;
-    return n;
+    return n | (idx << 8);
+}
+// the callers' form: generic pointers in, the new MT19937 index through idx_io
+template <bool RING_LDS>
+DEV int refill_requests_t(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req, const double *src_cum,
+                          const double *dst_cum, const double *br_cum, int *idx_io, int N, int NBR, double lam_arrival,
+                          double lam_holding) {
+    const int r = refill_requests_as<RING_LDS>((orlg_lds_u32 *)mt, ring_iat, ring_ht, ring_req, (orlg_lds_cf64 *)src_cum,
+                                               (orlg_lds_cf64 *)dst_cum, (orlg_lds_cf64 *)br_cum, *idx_io, N, NBR, lam_arrival,
+                                               lam_holding);
+    *idx_io = r >> 8;
+    return r & 0xff;
+}
+DEV int refill_requests(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req, const double *src_cum,
+                        const double *dst_cum, const double *br_cum, int *idx_io, int N, int NBR, double lam_arrival,
+                        double lam_holding) {   // ring in HBM
+    return refill_requests_t<false>(mt, ring_iat, ring_ht, ring_req, src_cum, dst_cum, br_cum, idx_io, N, NBR, lam_arrival, lam_holding);
 }
 
 // ---------------------------------------------------------------------------------------- first fit
@@ -1100,7 +1128,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 }
                 ring_dirty = true;
                 ring_in_lds = true;
-                ring_cnt = refill_requests(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
+                ring_cnt = refill_requests_t<true>(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
                                            &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda);
                 ring_pos = 0;
                 SEC(7);
