@@ -478,23 +478,23 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         if (p.out_mask && act && gl == 0) {
             const size_t o = (size_t)t * p.B + env;
             const int om = p.out_mask;
-            if (om & (1 << ORLG_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_PATH])[o] = a_path;
-            if (om & (1 << ORLG_OUT_SLOT)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
-            if (om & (1 << ORLG_OUT_ACCEPTED)) reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
+            if (om & (1 << ORLG_OUT_PATH)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_PATH])[o] = a_path;
+            if (om & (1 << ORLG_OUT_SLOT)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
+            if (om & (1 << ORLG_OUT_ACCEPTED)) ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
             if (om & (1 << ORLG_OUT_REWARD))
-                reinterpret_cast<double *>(tb.outs[ORLG_OUT_REWARD])[o] =
+                ORLG_GPTR(double, tb.outs[ORLG_OUT_REWARD])[o] =
                     p.reward_mode == 1 ? (accepted ? 1.0 : -1.0) : (accepted ? 1.0 : 0.0);
             if (om & (1 << ORLG_OUT_REQUEST))
-                reinterpret_cast<int4 *>(tb.outs[ORLG_OUT_REQUEST])[o] = make_int4(req_sid, req_src, req_dst, br_val);
-            if (om & (1 << ORLG_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_ARRIVAL])[o] = req_arrival;
-            if (om & (1 << ORLG_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_HOLDING])[o] = req_holding;
-            if (om & (1 << ORLG_OUT_COMPACT)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
+                ORLG_GPTR(orlg_v4i, tb.outs[ORLG_OUT_REQUEST])[o] = orlg_v4i{req_sid, req_src, req_dst, br_val};
+            if (om & (1 << ORLG_OUT_ARRIVAL)) ORLG_GPTR(double, tb.outs[ORLG_OUT_ARRIVAL])[o] = req_arrival;
+            if (om & (1 << ORLG_OUT_HOLDING)) ORLG_GPTR(double, tb.outs[ORLG_OUT_HOLDING])[o] = req_holding;
+            if (om & (1 << ORLG_OUT_COMPACT)) ORLG_GPTR(double, tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
             if (om & (1 << ORLG_OUT_COMPACT_DIFF))
-                reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
+                ORLG_GPTR(double, tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
             if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_COMPACT)))
-                reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(lst + 2 * E, E);
+                ORLG_GPTR(double, tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(lst + 2 * E, E);
             if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_UTIL)))
-                reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(lst, E);
+                ORLG_GPTR(double, tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(lst, E);
         }
         new_service = 0;
 
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         {
             const bool done = act && eproc == p.episode_length;
             if (act && gl == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
-                reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
+                ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
             if (ballot(done && p.auto_reset)) {
                 // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
                 if (done && p.auto_reset) {

@@ -38,6 +38,10 @@ typedef uint64_t u64;
 #define DEV __device__ __forceinline__
 #define ORLG_INF_BITS 0x7ff0000000000000ull
 
+// Per-step output arrays: their addresses are kept in LDS (Tab::outs), and a pointer read from memory is a generic pointer --
+// every store through it would be a flat instruction, which waits on both memory counters.  They are global memory.
+typedef int orlg_v4i __attribute__((ext_vector_type(4)));
+#define ORLG_GPTR(T, v) ((T __attribute__((address_space(1))) *)(v))   // an output array: global memory, not a generic pointer
 // ---------------------------------------------------------------------------------------- wave helpers
 DEV void wave_sync() {
     // LDS hand-off between lanes of ONE wave: hardware executes a wave's LDS operations in order, the
@@ -1075,26 +1079,26 @@ DEV void rmsa_body(const OrlgParams &p) {
                 const size_t o = (size_t)t * p.B + env;
                 if (lane == 0) {
                     const int om = p.out_mask;
-                    if (om & (1 << ORLG_OUT_PATH)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_PATH])[o] = a_path;
-                    if (om & (1 << ORLG_OUT_SLOT)) reinterpret_cast<int32_t *>(tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
-                    if (om & (1 << ORLG_OUT_ACCEPTED)) reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
+                    if (om & (1 << ORLG_OUT_PATH)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_PATH])[o] = a_path;
+                    if (om & (1 << ORLG_OUT_SLOT)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
+                    if (om & (1 << ORLG_OUT_ACCEPTED)) ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_ACCEPTED])[o] = accepted ? 1 : 0;
                     if (om & (1 << ORLG_OUT_REWARD))
-                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_REWARD])[o] =
+                        ORLG_GPTR(double, tb.outs[ORLG_OUT_REWARD])[o] =
                             p.reward_mode == 1 ? (accepted ? 1.0 : -1.0) : (accepted ? 1.0 : 0.0);
                     if (om & (1 << ORLG_OUT_REQUEST))
-                        reinterpret_cast<int4 *>(tb.outs[ORLG_OUT_REQUEST])[o] =
-                            make_int4(req_sid, req_src, req_dst, tb.bit_rates[req_br]);
-                    if (om & (1 << ORLG_OUT_ARRIVAL)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_ARRIVAL])[o] = wv.wsc->req_arrival;
-                    if (om & (1 << ORLG_OUT_HOLDING)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_HOLDING])[o] = wv.wsc->req_holding;
-                    if (om & (1 << ORLG_OUT_COMPACT)) reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
+                        ORLG_GPTR(orlg_v4i, tb.outs[ORLG_OUT_REQUEST])[o] =
+                            orlg_v4i{req_sid, req_src, req_dst, tb.bit_rates[req_br]};
+                    if (om & (1 << ORLG_OUT_ARRIVAL)) ORLG_GPTR(double, tb.outs[ORLG_OUT_ARRIVAL])[o] = wv.wsc->req_arrival;
+                    if (om & (1 << ORLG_OUT_HOLDING)) ORLG_GPTR(double, tb.outs[ORLG_OUT_HOLDING])[o] = wv.wsc->req_holding;
+                    if (om & (1 << ORLG_OUT_COMPACT)) ORLG_GPTR(double, tb.outs[ORLG_OUT_COMPACT])[o] = comp_cur;
                     if (om & (1 << ORLG_OUT_COMPACT_DIFF))
-                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
+                        ORLG_GPTR(double, tb.outs[ORLG_OUT_COMPACT_DIFF])[o] = prev_compact - comp_cur;
                     // info["avg_link_compactness" | "avg_link_utilization"] (rmsa_env.py:311-322): np.mean over the
                     // links, taken here -- after the provisioning, before _next_service releases anything
                     if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_COMPACT)))
-                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(wv.lst + 2 * E, E);
+                        ORLG_GPTR(double, tb.outs[ORLG_OUT_AVG_LINK_COMPACT])[o] = np_mean(wv.lst + 2 * E, E);
                     if (FULL && (om & (1 << ORLG_OUT_AVG_LINK_UTIL)))
-                        reinterpret_cast<double *>(tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(wv.lst, E);
+                        ORLG_GPTR(double, tb.outs[ORLG_OUT_AVG_LINK_UTIL])[o] = np_mean(wv.lst, E);
                 }
             }
             new_service = 0;
@@ -1198,7 +1202,7 @@ DEV void rmsa_body(const OrlgParams &p) {
         if (STEPK) {
             const bool done = (eproc == p.episode_length);
             if (lane == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
-                reinterpret_cast<uint8_t *>(tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
+                ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
             if (done && p.auto_reset) {
                 // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
                 for (int i = lane; i < NBR; i += 64) { wv.hist[2 * NBR + i] = 0; wv.hist[3 * NBR + i] = 0; }

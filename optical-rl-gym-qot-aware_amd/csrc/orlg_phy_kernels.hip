@@ -1272,8 +1272,6 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
 // victims by itself: the record is used only when its first victim is the one looked up (anything else is a plain load).
 // (Requesting the service's channel_state list, node weights and the queue's last record ahead as well was measured: no
 // gain, four more registers held across the step.)
-typedef int orlg_v4i __attribute__((ext_vector_type(4)));
-#define ORLG_GPTR(T, v) ((T __attribute__((address_space(1))) *)(v))   // an output array: global memory, not a generic pointer
 struct ReleaseAhead {
     int q;            // queue index of the looked-up service, -1: none
     uint32_t rec;     // lane < 12: dword `lane` of its record
