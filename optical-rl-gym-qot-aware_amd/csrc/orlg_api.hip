@@ -571,16 +571,20 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     // the four-environments-per-wave kernel: one environment's LDS region (no MT19937 state, no arrival ring, scalars in
     // registers), four per wave + the wave's MT19937 staging buffer; as many waves per workgroup as the LDS holds
     {
+        // a wave's region is array-major: the four environments' occupancy bitmaps behind each other, then their link statistics,
+        // span caches, release times, descriptors -- exactly as four consecutive environments lie in the HBM arrays, so a quad's
+        // occupancy / statistics / span cache move as ONE linear copy by all 64 lanes (uniform base + lane offset); g_* = offset of
+        // the array in the wave's region, row g's slice starts g * (slice bytes) further
         int go = 0;
-        p.g_occ = go; go = up16(go + p.NW * 8);
-        p.g_qtime = go; go = up16(go + Q * 8);
-        p.g_qdesc = go; go = up16(go + Q * 4);
-        p.g_lstat = go; if (c->stats_level >= ORLG_STATS_FULL) go = up16(go + 4 * E * 8);
+        p.g_occ = go; go = up16(go + 4 * p.NW * 8);
+        p.g_lstat = go; if (c->stats_level >= ORLG_STATS_FULL) go = up16(go + 4 * 4 * E * 8);
         p.g_hist = go;   // (unused: the four-environments-per-wave kernel updates the histograms in HBM)
-        p.g_lint = go; go = up16(go + p.lint_stride * 4);
-        p.g_env_bytes = go;
+        p.g_lint = go; go = up16(go + 4 * p.lint_stride * 4);
+        p.g_qtime = go; go = up16(go + 4 * Q * 8);
+        p.g_qdesc = go; go = up16(go + 4 * Q * 4);
+        p.g_env_bytes = (go + 3) / 4;   // (per environment, for messages)
         p.g_mt = up16(ORLG_MT_N * 4);   // the workgroup's MT19937 staging buffer (then its lock word), in front of the waves' regions
-        p.g_wave_bytes = 4 * go;
+        p.g_wave_bytes = go;
         e->group_wpb = 0;
         for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb; cand--)
             if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;

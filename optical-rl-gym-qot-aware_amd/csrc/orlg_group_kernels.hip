@@ -203,6 +203,15 @@ DEV void row_copy16(void *dst, const void *src, int bytes, int gl) {
     uint4 *d16 = reinterpret_cast<uint4 *>(dst);
     for (int i = gl; i < n16; i += ORLG_GL) d16[i] = s16[i];
 }
+// A quad's slices of one array between HBM and LDS: `bytes` (a multiple of 8) from a wave-uniform source by all 64 lanes, 16
+// bytes per lane and pass (the quad's first environment is a multiple of four: 32-byte aligned for every array copied this way)
+DEV void quad_copy(void *dst, const void *src, int bytes, int lane) {
+    const int n16 = bytes >> 4;
+    const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d16 = reinterpret_cast<uint4 *>(dst);
+    for (int i = lane; i < n16; i += ORLG_WAVE) d16[i] = s16[i];
+    if ((bytes & 8) && lane == 0) reinterpret_cast<u64 *>(dst)[2 * n16] = reinterpret_cast<const u64 *>(src)[2 * n16];
+}
 DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
     for (int i = gl; i < n; i += ORLG_GL) dst[i] = src[i];
 }
@@ -222,12 +231,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     if (threadIdx.x == 0) *mt_lock = 0;
     __syncthreads();
     unsigned char *wbase = smem + p.l_shared_bytes + p.g_mt + 16 + (size_t)wib * p.g_wave_bytes;
-    unsigned char *eb = wbase + g * p.g_env_bytes;  // this row's environment
-    u64 *occ = reinterpret_cast<u64 *>(eb + p.g_occ);
-    double *qtime = reinterpret_cast<double *>(eb + p.g_qtime);
-    uint32_t *qdesc = reinterpret_cast<uint32_t *>(eb + p.g_qdesc);
-    double *lst = reinterpret_cast<double *>(eb + p.g_lstat);
-    int32_t *lint = reinterpret_cast<int32_t *>(eb + p.g_lint);
+    // this row's environment: slice g of every array of the wave's region (array-major: OrlgParams::g_occ ...)
+    u64 *occ = reinterpret_cast<u64 *>(wbase + p.g_occ) + g * p.NW;
+    double *qtime = reinterpret_cast<double *>(wbase + p.g_qtime) + g * p.Q;
+    uint32_t *qdesc = reinterpret_cast<uint32_t *>(wbase + p.g_qdesc) + g * p.Q;
+    double *lst = reinterpret_cast<double *>(wbase + p.g_lstat) + g * 4 * p.E;
+    int32_t *lint = reinterpret_cast<int32_t *>(wbase + p.g_lint) + g * p.lint_stride;
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
     constexpr bool NET = STATS >= 1;
@@ -262,13 +271,26 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     const int env = act ? env_raw : p.B - 1;
 
     // ------------------------------------------------------------------ HBM -> LDS
-    row_copy8(occ, p.occ + (size_t)env * NW, NW, gl);
-    if (FULL) row_copy16(lst, p.lstat + (size_t)env * 4 * E, 4 * E * 8, gl);
+    // occupancy, link statistics, span caches of the quad's environments: linear copies (rows past the batch's end take a
+    // copy of the last environment's slices afterwards)
+    const int env0 = quad * ORLG_GE;
+    const int nact = p.B - env0 < ORLG_GE ? p.B - env0 : ORLG_GE;
+    quad_copy(wbase + p.g_occ, p.occ + (size_t)env0 * NW, nact * NW * 8, lane);
+    if (FULL) quad_copy(wbase + p.g_lstat, p.lstat + (size_t)env0 * 4 * E, nact * 4 * E * 8, lane);
     // the bit-rate histograms are only ever incremented (and zeroed at an episode's end): they stay in HBM and take L2 atomics
     // without return -- 336 bytes of LDS per environment decide how many waves a CU keeps resident.  Every access
     // is an atomic, so that the updates of one address arrive at L2 in program order.
     int32_t *ghist = p.hist + (size_t)env * 4 * NBR;
-    if (NET) row_copy16(lint, p.lint + (size_t)env * p.lint_stride, p.lint_stride * 4, gl);
+    if (NET) quad_copy(wbase + p.g_lint, p.lint + (size_t)env0 * p.lint_stride, nact * p.lint_stride * 4, lane);
+    if (nact < ORLG_GE) {   // the batch's last quad only
+        wave_sync();
+        if (!act) {
+            const int gs_ = nact - 1;
+            for (int i = gl; i < NW; i += ORLG_GL) occ[i] = (reinterpret_cast<u64 *>(wbase + p.g_occ) + gs_ * NW)[i];
+            if (FULL) for (int i = gl; i < 4 * E; i += ORLG_GL) lst[i] = (reinterpret_cast<double *>(wbase + p.g_lstat) + gs_ * 4 * E)[i];
+            if (NET) for (int i = gl; i < p.lint_stride; i += ORLG_GL) lint[i] = (reinterpret_cast<int32_t *>(wbase + p.g_lint) + gs_ * p.lint_stride)[i];
+        }
+    }
     const OrlgEnvScalars *gs = p.scal + env;
     double current_time = gs->current_time, req_arrival = gs->req_arrival, req_holding = gs->req_holding;
     double g_thr = gs->g_throughput, g_comp = gs->g_compactness, g_lu = gs->g_last_update;
@@ -621,8 +643,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     // ------------------------------------------------------------------ LDS -> HBM
     SEC(13);  // state store
     wave_sync();
+    {
+        const int env0 = quad * ORLG_GE;
+        const int nact = p.B - env0 < ORLG_GE ? p.B - env0 : ORLG_GE;
+        quad_copy(p.occ + (size_t)env0 * NW, wbase + p.g_occ, nact * NW * 8, lane);
+        if (FULL) quad_copy(p.lstat + (size_t)env0 * 4 * E, wbase + p.g_lstat, nact * 4 * E * 8, lane);
+        if (NET) quad_copy(p.lint + (size_t)env0 * p.lint_stride, wbase + p.g_lint, nact * p.lint_stride * 4, lane);
+    }
     if (act) {
-        row_copy8(p.occ + (size_t)env * NW, occ, NW, gl);
         {
             // the ring from where its head was at the start (slots popped since then hold (+inf, 0)) to its last entry
             double *gqt = p.qtime + (size_t)env * Q;
@@ -637,8 +665,6 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 gqt[pos] = qtime[pos]; gqd[pos] = qdesc[pos];
             }
         }
-        if (FULL) row_copy16(p.lstat + (size_t)env * 4 * E, lst, 4 * E * 8, gl);
-        if (NET) row_copy16(p.lint + (size_t)env * p.lint_stride, lint, p.lint_stride * 4, gl);
         OrlgEnvScalars *go = p.scal + env;
         if (gl < 8) go->c[gl] = cnt;
         if (gl == 8) {
