@@ -314,10 +314,19 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     {
         const double *gqt = p.qtime + (size_t)env * Q;
         const uint32_t *gqd = p.qdesc + (size_t)env * Q;
-        for (int j = gl; j < q_n; j += ORLG_GL) {
+        for (int j = gl; j < q_n; j += 2 * ORLG_GL) {   // two slots per lane and pass: four requests in flight, then four writes
             int pos = q_head + j;
             pos -= pos >= Q ? Q : 0;
-            qtime[pos] = gqt[pos]; qdesc[pos] = gqd[pos];
+            int pos2 = pos + ORLG_GL;
+            pos2 -= pos2 >= Q ? Q : 0;
+            const bool two = j + ORLG_GL < q_n;
+            const double t0 = gqt[pos];
+            const uint32_t d0 = gqd[pos];
+            double t1 = 0.0;
+            uint32_t d1 = 0u;
+            if (two) { t1 = gqt[pos2]; d1 = gqd[pos2]; }
+            qtime[pos] = t0; qdesc[pos] = d0;
+            if (two) { qtime[pos2] = t1; qdesc[pos2] = d1; }
         }
     }
     wave_sync();
