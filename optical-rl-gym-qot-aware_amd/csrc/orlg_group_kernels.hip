@@ -15,6 +15,8 @@
 // can continue a batch the other one stepped, and the reset kernel is shared.  The MT19937 state and the ring of pre-generated
 // arrivals stay in HBM: a row reads its next arrival one step ahead, and a refill (every ~62 steps per environment) is done
 // by the whole wave for one environment at a time through a per-wave LDS staging buffer (refill_requests, unchanged).
+// The wave's LDS region is array-major (four occupancy bitmaps, then four link-statistics blocks, ...: OrlgParams::g_occ ...),
+// as four consecutive environments lie in the HBM arrays: a quad's state moves as linear copies by all 64 lanes.
 //
 // Policies: the first-fit family (shortest path / shortest available path, path-only agent actions), the DeepRMSA block family
 // (its two heuristics and the agent's (path, block) action), load balancing (llp_ff) and external (path, slot) actions.  Reference: the same lines of rmsa_env.py as orlg_kernels.hip cites.
