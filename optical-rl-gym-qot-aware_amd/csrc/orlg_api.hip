@@ -47,6 +47,8 @@ struct orlg_env {
     // (AUTO falls back to WAVE when the shape does not fit the kernel's LDS budget)
     int group_mode, group_wpb;   // group_wpb: the most waves per workgroup the LDS holds
     int group_resident[ORLG_GROUP_WAVES + 1];   // resident workgroups by waves per workgroup (0 = not asked yet)
+    int group_wpb_hq, group_wave_bytes_hq;      // the same for launches that leave the release queue in HBM (orlg_rmsa_group_kernel<.., true>)
+    int group_resident_hq[ORLG_GROUP_WAVES + 1];
     size_t group_lds_bytes;
     int num_cu;
     uint32_t ticket_base;
@@ -266,40 +268,48 @@ static masks_kernel_t pick_masks(int W) {
 
 // the step kernel with four environments per wave: first-fit policies and external (path, slot) actions
 static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
-    rmsa_kernel_t k = pick_group(e->W, p.stats_level);
+    // launches of very few steps leave the release queue in HBM (the kernel's HBMQ instantiation): without the queue's slices an
+    // environment takes half the LDS, and such a launch is bound by the waves a CU keeps resident
+    const bool hq = p.n_steps <= ORLG_DIRECT_STEPS && e->group_wpb_hq > e->group_wpb;
+    const int wave_bytes = hq ? e->group_wave_bytes_hq : p.g_wave_bytes;
+    const int wpb_max = hq ? e->group_wpb_hq : e->group_wpb;
+    int *resident = hq ? e->group_resident_hq : e->group_resident;
+    rmsa_kernel_t k = pick_group(e->W, p.stats_level + (hq ? 4 : 0));
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->group_lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb_max * wave_bytes)));
     const int n_quads = (p.B + 3) / 4;
     // Waves per workgroup: as many as the LDS holds when the batch keeps every CU busy for several rounds (more resident waves
     // per SIMD hide more latency); fewer when that would leave CUs idle or the last round mostly empty.  A round of w waves per
     // CU costs about w + 1.5 (measured: 10 waves per CU step 3 % more environments per second than 8); few rounds count whole.
-    int wpb = e->group_wpb;
+    int wpb = wpb_max;
     {
         double best = 1e300;
-        for (int w = e->group_wpb; w >= 1; --w) {
+        for (int w = wpb_max; w >= 1; --w) {
             const double rounds = (double)n_quads / ((double)e->num_cu * w);
             // (short launches stride statically over the quads: whole rounds; long ones draw tickets: the last round is partial)
             const double cost = ((rounds < 3.0 || p.n_steps <= 16) ? std::ceil(rounds) : rounds + 0.5) * (w + 1.5);
             if (cost < best - 1e-9) { best = cost; wpb = w; }
         }
     }
-    const size_t lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb * p.g_wave_bytes;
-    if (e->group_resident[wpb] <= 0) {
+    const size_t lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb * wave_bytes;
+    if (resident[wpb] <= 0) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, lds_bytes));
-        e->group_resident[wpb] = (nb > 0 ? nb : 1) * e->num_cu;
+        resident[wpb] = (nb > 0 ? nb : 1) * e->num_cu;
     }
     int nblocks = (n_quads + wpb - 1) / wpb;
-    if (nblocks > e->group_resident[wpb]) nblocks = e->group_resident[wpb];
+    if (nblocks > resident[wpb]) nblocks = resident[wpb];
     OrlgParams q = p;
+    q.g_wave_bytes = wave_bytes;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
     if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads;  // one draw per quad of environments a wave takes on
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
-    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d> grid=%d block=%d lds=%zu", e->W, p.stats_level,
-             nblocks, ORLG_WAVE * wpb, lds_bytes);
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d%s> grid=%d block=%d lds=%zu", e->W, p.stats_level,
+             hq ? ",true" : "", nblocks, ORLG_WAVE * wpb, lds_bytes);
     return ORLG_OK;
 }
 
@@ -589,7 +599,11 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb; cand--)
             if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
         e->group_lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)e->group_wpb * p.g_wave_bytes;
-        for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = 0;
+        for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = e->group_resident_hq[w] = 0;
+        e->group_wave_bytes_hq = p.g_qtime;   // the region ends where the ring's slices would begin (they are the last arrays)
+        e->group_wpb_hq = 0;
+        for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb_hq; cand--)
+            if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * e->group_wave_bytes_hq <= 160 * 1024) e->group_wpb_hq = cand;
         e->group_mode = c->step_kernel;
         const char *gm = getenv("ORLG_GROUP_KERNEL");  // tooling override: 0 = WAVE, 1 = GROUP
         if (gm && (gm[0] == '0' || gm[0] == '1')) e->group_mode = gm[0] == '1' ? ORLG_KERNEL_GROUP : ORLG_KERNEL_WAVE;

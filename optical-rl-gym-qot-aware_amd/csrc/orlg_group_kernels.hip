@@ -218,7 +218,11 @@ DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
     for (int i = gl; i < n; i += ORLG_GL) dst[i] = src[i];
 }
 
-template <int W, int STATS>
+// HBMQ: launches of very few steps (the agent-driven loop) leave the release queue where it is, in HBM: staged in LDS it is
+// half of an environment's footprint there (its capacity, not its live part, sizes the region), and a one-step launch is
+// bound by how many waves a CU keeps resident, not by the queue's latency.  The ring logic is the same code on
+// global pointers; OrlgParams::g_wave_bytes of such a launch ends where the ring's LDS slices would begin.
+template <int W, int STATS, bool HBMQ = false>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3) / 4) void orlg_rmsa_group_kernel(const OrlgParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
@@ -235,8 +239,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     unsigned char *wbase = smem + p.l_shared_bytes + p.g_mt + 16 + (size_t)wib * p.g_wave_bytes;
     // this row's environment: slice g of every array of the wave's region (array-major: OrlgParams::g_occ ...)
     u64 *occ = reinterpret_cast<u64 *>(wbase + p.g_occ) + g * p.NW;
-    double *qtime = reinterpret_cast<double *>(wbase + p.g_qtime) + g * p.Q;
-    uint32_t *qdesc = reinterpret_cast<uint32_t *>(wbase + p.g_qdesc) + g * p.Q;
+    double *qtime = nullptr;
+    uint32_t *qdesc = nullptr;
+    if constexpr (!HBMQ) {
+        qtime = reinterpret_cast<double *>(wbase + p.g_qtime) + g * p.Q;
+        qdesc = reinterpret_cast<uint32_t *>(wbase + p.g_qdesc) + g * p.Q;
+    }
     double *lst = reinterpret_cast<double *>(wbase + p.g_lstat) + g * 4 * p.E;
     int32_t *lint = reinterpret_cast<int32_t *>(wbase + p.g_lint) + g * p.lint_stride;
 
@@ -313,7 +321,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     // only the live part of the ring moves between HBM and LDS (a launch of one step would otherwise spend most of its
     // traffic on empty slots); LDS slots outside it are never read
     const int q_head0 = q_head;
-    {
+    if constexpr (HBMQ) {
+        qtime = p.qtime + (size_t)env * Q;
+        qdesc = p.qdesc + (size_t)env * Q;
+    } else {
         const double *gqt = p.qtime + (size_t)env * Q;
         const uint32_t *gqd = p.qdesc + (size_t)env * Q;
         for (int j = gl; j < q_n; j += 2 * ORLG_GL) {   // two slots per lane and pass: four requests in flight, then four writes
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             // ---- _add_release (optical_network_env.py:178-189): the entries that are released later move up one slot (from the
             // top chunk of 16 down: a chunk's reads precede its writes), the new one takes the slot that opens -- each row its own
             const double rel = req_arrival + req_holding;
-            bool ins = accepted;
+            bool ins = accepted && (act || !HBMQ);   // (a row past the batch's end must not touch the last environment's ring in HBM)
             if (ins && q_n >= Q) { q_overflow = 1; ins = false; }
             bool found = !ins;
             int r = 0, j0 = (q_n - 1) & ~(ORLG_GL - 1);   // q_n == 0: j0 < 0, nothing to move
@@ -662,7 +673,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         if (NET) quad_copy(p.lint + (size_t)env0 * p.lint_stride, wbase + p.g_lint, nact * p.lint_stride * 4, lane);
     }
     if (act) {
-        {
+        if constexpr (!HBMQ) {
             // the ring from where its head was at the start (slots popped since then hold (+inf, 0)) to its last entry
             double *gqt = p.qtime + (size_t)env * Q;
             uint32_t *gqd = p.qdesc + (size_t)env * Q;

@@ -9,7 +9,16 @@
 #define ORLG_CAT2(a, b) a##b
 #define ORLG_CAT(a, b) ORLG_CAT2(a, b)
 
+// stats = statistics level (0..2), + 4: the instantiation that leaves the release queue in HBM (launches of very few steps)
 orlg_rmsa_kernel_t ORLG_CAT(orlg_group_kernel_W, ORLG_INST_W)(int stats) {
     constexpr int W = ORLG_INST_W;
-    return stats == 0 ? orlg_rmsa_group_kernel<W, 0> : stats == 1 ? orlg_rmsa_group_kernel<W, 1> : orlg_rmsa_group_kernel<W, 2>;
+    switch (stats) {
+        case 0: return orlg_rmsa_group_kernel<W, 0>;
+        case 1: return orlg_rmsa_group_kernel<W, 1>;
+        case 2: return orlg_rmsa_group_kernel<W, 2>;
+        case 4: return orlg_rmsa_group_kernel<W, 0, true>;
+        case 5: return orlg_rmsa_group_kernel<W, 1, true>;
+        case 6: return orlg_rmsa_group_kernel<W, 2, true>;
+        default: return nullptr;
+    }
 }
