@@ -211,7 +211,21 @@ DEV void quad_copy(void *dst, const void *src, int bytes, int lane) {
     const int n16 = bytes >> 4;
     const uint4 *s16 = reinterpret_cast<const uint4 *>(src);
     uint4 *d16 = reinterpret_cast<uint4 *>(dst);
-    for (int i = lane; i < n16; i += ORLG_WAVE) d16[i] = s16[i];
+    // four requests per lane before the first write: a quad's occupancy (3.5 KB) is one round trip, not four
+    for (int i0 = 0; i0 < n16; i0 += 4 * ORLG_WAVE) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * ORLG_WAVE + lane;
+            v[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n16) v[k] = s16[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * ORLG_WAVE + lane;
+            if (i < n16) d16[i] = v[k];
+        }
+    }
     if ((bytes & 8) && lane == 0) reinterpret_cast<u64 *>(dst)[2 * n16] = reinterpret_cast<const u64 *>(src)[2 * n16];
 }
 DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
