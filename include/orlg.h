@@ -79,7 +79,9 @@ typedef struct orlg_rmsa_config {
 
 /* Two step kernels share one state format.  WAVE: one wavefront per environment (every policy).  GROUP: four environments
  * per wavefront, 16 lanes each (every policy too).  AUTO picks GROUP for a batch larger
- * than the WAVE kernel's resident wavefronts (4096 on MI355X), WAVE otherwise.  Results are identical bit for bit. */
+ * than the WAVE kernel's resident wavefronts (4096 on MI355X), WAVE otherwise; launches of at most four steps (the
+ * agent-driven loop: one orlg_step per action) run an instantiation of GROUP that leaves the release queue in HBM.
+ * Results are identical bit for bit, and so is the saved state. */
 enum { ORLG_KERNEL_AUTO = 0, ORLG_KERNEL_WAVE = 1, ORLG_KERNEL_GROUP = 2 };
 
 enum {
