@@ -303,6 +303,38 @@ def test_path_masks_query(nsfnet):
     o.close()
 
 
+def test_group_kernel_short_launches_keep_the_queue_in_hbm(nsfnet):
+    """Launches of at most four steps run the group kernel's instantiation that leaves the release queue in HBM (half the LDS
+    per environment): a batch that is not a multiple of four (the idle row must not touch the last environment's ring), stepped
+    1 / 3 / 4 steps at a time across episode ends, against an uninterrupted run of the wave-per-environment kernel -- outputs,
+    counters, link statistics and the saved state byte for byte."""
+    kw = dict(num_spectrum_resources=320, load=80, mean_service_holding_time=25, episode_length=60, seed=33)
+    B = 9
+    outs = ("act_path", "act_slot", "accepted", "arrival", "network_compactness", "done")
+    ref = make_batched(nsfnet, kw, B, step_kernel="wave")
+    env = make_batched(nsfnet, kw, B, step_kernel="group")
+    t_ref = ref.run("sap_ff", 400, outputs=outs, auto_reset=True)
+    parts, left, sizes = [], 400, (1, 3, 4, 1, 2)
+    i = 0
+    while left:
+        n = min(sizes[i % len(sizes)], left)
+        parts.append(env.run("sap_ff", n, outputs=outs, auto_reset=True))
+        assert ",true>" in env.last_kernel(), env.last_kernel()
+        left -= n
+        i += 1
+    for k in outs:
+        assert np.array_equal(t_ref[k], np.concatenate([q[k] for q in parts])), k
+    ca, cb = ref.counters(), env.counters()
+    for name in ca:
+        assert np.array_equal(ca[name], cb[name]), name
+    la, lb = ref.link_stats(), env.link_stats()
+    for name in la:
+        assert np.array_equal(la[name], lb[name]), name
+    assert np.array_equal(ref.save_state(), env.save_state())
+    ref.close()
+    env.close()
+
+
 def test_kernels_continue_each_other(nsfnet):
     """One state format: a batch stepped by the wave-per-environment kernel is handed (save_state / load_state) to the
     four-environments-per-wave kernel and back; outputs and final state equal an uninterrupted run."""
