@@ -1325,6 +1325,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
     int *opb = opa + p.obs_dim;                            // [obs_dim] second operand (free runs) where needed
     const int N = p.N, K = p.K, S = p.S, J = p.j;
     const int PW = 2 * J + 3, head = 1 + 2 * N;
+    const uint32_t pw_inv = (65536u + (uint32_t)PW - 1u) / (uint32_t)PW;
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
     const bool wide = (p.NW & 1) == 0;
     for (int env = blockIdx.x * (int)(blockDim.x >> 6) + wib; env < p.B; env += n_waves) {
@@ -1428,7 +1429,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
             } else if (i < head) {
                 fixed = true; fixed_val = (i - 1 == mn || i - 1 == N + mx) ? 1.0 : 0.0;   // one-hot endpoints
             } else {
-                const int r = i - head, c = r % PW;
+                // (r / PW by multiply-shift: exact for every r < 64 * PW, PW <= 35, checked exhaustively; r < K * PW with K <= 64 -- an integer division by a run-time value is ~30 instructions)
+                const int r = i - head, c = r - (int)(((uint32_t)r * pw_inv) >> 16) * PW;
                 const int v = opa[i];
                 if (c < 2 * J) {
                     if (v < 0) { fixed = true; fixed_val = -1.0; }
@@ -1445,7 +1447,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
                 }
             }
             res = num / den;
-            if (tail) res = (res - 4) / 4;
+            if (tail) res = (res - 4) * 0.25;   // (x / 4 is x * 0.25 exactly)
             gout[i] = fixed ? fixed_val : res;
         }
         wave_sync();
