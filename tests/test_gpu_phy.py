@@ -150,6 +150,46 @@ def test_phy_external_actions(device_log_in_oracle):
     env.close()
 
 
+@pytest.mark.parametrize("metric", ["cut", "rss"])
+def test_phy_external_actions_with_defragmentation(metric, device_log_in_oracle):
+    """The single-environment gym surface steps with external actions: the same with the periodic defragmentation inside the
+    step (the external-action instantiation of the kernel + defragmentation), grooming on, per-step metrics written -- the
+    oracle's own bmfa decisions replayed one launch per step, compared step by step."""
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    kw = dict(load=1300, mean_service_holding_time=25, episode_length=90, seed=41, grooming=True, defrag_period=6, number_moves=5,
+              metric=metric)
+    env = make_env(topo, tables, kw, 3)
+    oracles = [phy_oracle_from_kwargs(topo, tables, kw, seed=41 + i) for i in range(3)]
+    policy = "bmfa" if metric == "cut" else "bmfa_rss"
+    for t in range(260):
+        paths = np.full(3, -2, np.int32)
+        chans = np.full((3, 14), -1, np.int16)
+        acts = []
+        for i, o in enumerate(oracles):
+            a = o.policy(policy)
+            paths[i] = a.path
+            for q in range(a.n):
+                chans[i, q] = a.ch[q] | (int(a.used[q]) << 9)
+            acts.append(a)
+        r = env.run("external", 1, act_path=paths, act_channels=chans,
+                    outputs=("accepted", "number_cuts_total", "rss_total_metric", "defrag_counters"), auto_reset=True)
+        assert env.last_kernel().startswith("orlg_phy_kernel<5,true,false,-1>"), env.last_kernel()
+        for i, o in enumerate(oracles):
+            res = o.step(acts[i])
+            assert r["accepted"][0, i] == res.accepted, (t, i)
+            assert r["number_cuts_total"][0, i] == res.number_cuts_total, (t, i)
+            assert r["rss_total_metric"][0, i] == res.rss_total_metric, (t, i)
+            if res.done:
+                o.reset(only_episode_counters=True)
+    av, cnt = env.available_channels(), env.counters()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(av[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        assert env.channel_state(i) == o.channel_state(), i
+        o.close()
+    env.close()
+
+
 def test_phy_external_virtual_layer_actions(device_log_in_oracle):
     """External actions incl. the virtual layer (path = 20 + k-path, per-channel shares): replay the oracle's sapff."""
     z, meta = load_golden("phy_us14_s10_sapff")
