@@ -582,7 +582,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 wave_sync();
                 const int got = refill_requests(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
                                                 p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N,
-                                                NBR, p.arrival_lambda, p.holding_lambda);
+                                                NBR, p.arrival_lambda, p.holding_lambda, env_s);
                 m0 = l_mt[lane]; m1 = l_mt[lane + 64];
                 if (lane < 156 - 128) m2 = l_mt[lane + 128];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's reads of the buffer are done

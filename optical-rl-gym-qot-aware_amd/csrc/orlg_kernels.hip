@@ -233,12 +233,17 @@ typedef __attribute__((address_space(1))) double orlg_glb_f64;
 template <bool RING_LDS>
 __device__ __noinline__ int refill_requests_as(orlg_lds_u32 *mt, void *ring_iat_v, void *ring_ht_v, void *ring_req_v,
                                                orlg_lds_cf64 *src_cum, orlg_lds_cf64 *dst_cum, orlg_lds_cf64 *br_cum, int idx,
-                                               int N, int NBR, double lam_arrival, double lam_holding) {
+                                               int N, int NBR, double lam_arrival, double lam_holding, int env) {
     // out of line on purpose: it runs once per ~62 steps and must not add register pressure to the step loop
     const int lane = threadIdx.x & 63;
     const double ylam_arrival = recip_refine(lam_arrival), ylam_holding = recip_refine(lam_holding);
     int n = (2 * ORLG_MT_N - idx) / 10;
     n = n > ORLG_RING ? ORLG_RING : n;
+    // A freshly seeded generator (idx == 624: every environment's first refill) hands out 62 - env % 56 requests instead of 62.
+    // The request stream is the same whatever a refill's size; what changes is WHEN the environments run dry: batches stepped
+    // one launch per step (agent-driven) otherwise refill all at once every 62nd launch, one after the other behind the
+    // workgroup's staging-buffer lock.
+    if (idx == ORLG_MT_N) { const int cap = 62 - env % 56; n = n > cap ? cap : n; }
     uint32_t w[10];
     const int g0 = idx + 10 * lane;
 #pragma unroll
@@ -292,17 +297,17 @@ __device__ __noinline__ int refill_requests_as(orlg_lds_u32 *mt, void *ring_iat_
 template <bool RING_LDS>
 DEV int refill_requests_t(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req, const double *src_cum,
                           const double *dst_cum, const double *br_cum, int *idx_io, int N, int NBR, double lam_arrival,
-                          double lam_holding) {
+                          double lam_holding, int env) {
     const int r = refill_requests_as<RING_LDS>((orlg_lds_u32 *)mt, ring_iat, ring_ht, ring_req, (orlg_lds_cf64 *)src_cum,
                                                (orlg_lds_cf64 *)dst_cum, (orlg_lds_cf64 *)br_cum, *idx_io, N, NBR, lam_arrival,
-                                               lam_holding);
+                                               lam_holding, env);
     *idx_io = r >> 8;
     return r & 0xff;
 }
 DEV int refill_requests(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req, const double *src_cum,
                         const double *dst_cum, const double *br_cum, int *idx_io, int N, int NBR, double lam_arrival,
-                        double lam_holding) {   // ring in HBM
-    return refill_requests_t<false>(mt, ring_iat, ring_ht, ring_req, src_cum, dst_cum, br_cum, idx_io, N, NBR, lam_arrival, lam_holding);
+                        double lam_holding, int env) {   // ring in HBM
+    return refill_requests_t<false>(mt, ring_iat, ring_ht, ring_req, src_cum, dst_cum, br_cum, idx_io, N, NBR, lam_arrival, lam_holding, env);
 }
 
 // ---------------------------------------------------------------------------------------- first fit
@@ -1133,7 +1138,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 ring_dirty = true;
                 ring_in_lds = true;
                 ring_cnt = refill_requests_t<true>(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
-                                           &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda);
+                                           &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda, env);
                 ring_pos = 0;
                 SEC(7);
             }

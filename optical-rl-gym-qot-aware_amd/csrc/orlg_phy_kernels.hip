@@ -1957,7 +1957,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 int idx_s = mt_idx;
                 const int got = refill_requests(mt_lds, kq->ring_iat + (size_t)env * ORLG_RING, kq->ring_ht + (size_t)env * ORLG_RING,
                                                 kq->ring_req + (size_t)env * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N, NBR,
-                                                p.arrival_lambda, p.holding_lambda);
+                                                p.arrival_lambda, p.holding_lambda, env);
                 m0 = l_mt[lane]; m1 = l_mt[lane + 64];
                 if (lane < 156 - 128) m2 = l_mt[lane + 128];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's reads of the buffer are done
