@@ -303,6 +303,28 @@ def test_path_masks_query(nsfnet):
     o.close()
 
 
+@pytest.mark.parametrize("batch", [9, 11])
+def test_group_kernel_odd_word_count_partial_quad(batch, device_log_in_oracle):
+    """JPN12: 17 links x 5 words = 85 words per bitmap (odd), and a batch whose last quad holds one / three environments: the
+    quad-wide linear copies end on an 8-byte tail.  Long and one-step launches of the group kernel against the oracle."""
+    topo = load_topology("jpn12_5-paths_6-modulations")
+    kw = dict(num_spectrum_resources=320, load=40, mean_service_holding_time=25, episode_length=70, seed=55)
+    env = make_batched(topo, kw, batch, step_kernel="group")
+    outs = ("act_path", "act_slot", "accepted", "network_compactness")
+    parts = [env.run("sap_ff", n, outputs=outs, auto_reset=True) for n in (90, 1, 1, 2, 150, 1, 55)]
+    tr = {k: np.concatenate([q[k] for q in parts]) for k in outs}
+    occ = env.occupancy_words()
+    for i in (0, batch - 2, batch - 1):
+        o = oracle_env_from_kwargs(topo, kw, seed=55 + i)
+        ot = o.run("sap_ff", 300, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["act_slot"][:, i], ot["act_slot"]), i
+        assert np.array_equal(tr["network_compactness"][:, i], ot["network_compactness"]), i
+        o.close()
+    assert occ.shape[0] == batch
+    env.close()
+
+
 def test_group_kernel_short_launches_keep_the_queue_in_hbm(nsfnet):
     """Launches of at most four steps run the group kernel's instantiation that leaves the release queue in HBM (half the LDS
     per environment): a batch that is not a multiple of four (the idle row must not touch the last environment's ring), stepped
