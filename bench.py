@@ -13,8 +13,9 @@ load 50, B = 65 536 environments per GPU, shortest-available-path first fit run 
 statistics.  Sub-records (N=1 only), each timed the same way with its own roofline block and kernel name:
     rmsa_b4096        BASELINE configs[1] (the same env x 4096)
     phy_us14_b4096    BASELINE configs[2]: QoT-aware RMSA, US14, load 1400, bmfa -- with number_cuts_total / rss_total_metric
-                      written every step as the reference's step() does (lead), without them, and with the periodic
-                      defragmentation (defrag_period 10, number_moves 10)
+                      written every step as the reference's step() does (lead), without them, with the periodic
+                      defragmentation (defrag_period 10, number_moves 10), and with the GN-model OSNR gate of the chosen
+                      channels inside the step (configs[2] as BASELINE words it; parity unpinned by the reference)
     deeprmsa_b32768   BASELINE configs[3]: one launch + one observation build per step; also the PCIe-inclusive rate of
                       the agent loop (actions from host memory, observations copied back)
 Inputs are synthetic (the reference's own Poisson traffic generator run on the device) and all state is resident in HBM
@@ -62,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--queue-capacity", type=int, default=0, help="release-queue slots per environment (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
-    ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "deeprmsa"],
+    ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "phy_gn", "deeprmsa"],
                     help="run one workload only (profiling)")
     ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: ranks report their shard through gloo (launcher test)")
@@ -131,32 +132,32 @@ def load_pmc(key):
         return None
 
 
+ROOFLINE_NOTE = ("every roofline block: bound/achieved/frac = SURVEY 8(d) algorithmic bytes per env-step x env-steps per launch / mean "
+                 "launch time (HIP events on the kernel's stream), peak 8 TB/s; traffic = HBM bytes per launch from the FETCH_SIZE "
+                 "(x2, gfx950) + WRITE_SIZE passes in profiles/pmc.json; the state lives in LDS for a whole launch, so what binds is "
+                 "in valu_issue (wave-instructions/s against 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; valu_busy from the same counters)")
+
+
 def roofline_block(key, kernel, kernel_ms, A, env_steps_per_launch, batch):
     """HBM roofline by the SURVEY 8(d) accounting (what the contract asks for) + what the counters say binds the kernel."""
     achieved = A * env_steps_per_launch / (kernel_ms * 1e-3) / 1e9
     rate = env_steps_per_launch / (kernel_ms * 1e-3)
     rl = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-          "traffic": None, "traffic_unit": "bytes per launch", "kernel": kernel, "kernel_ms_per_launch": kernel_ms,
-          "algorithmic_bytes_per_env_step": A, "env_steps_per_launch": env_steps_per_launch,
-          "note": "bound/achieved/frac follow SURVEY 8(d)'s algorithmic-byte accounting; the state lives in LDS for a whole "
-                  "launch, so measured HBM traffic is far below it; what binds: VALU issue for the RMSA step kernels (valu_issue "
-                  "block: 83-99 % busy), the wave's own instruction latency for the QoT-aware step (valu_busy ~0.63: DESIGN 2.9), "
-                  "the state's HBM round trip for one-step launches (hbm_measured_GBps)"}
+          "traffic": None, "kernel": kernel, "kernel_ms_per_launch": kernel_ms,
+          "algorithmic_bytes_per_env_step": A, "env_steps_per_launch": env_steps_per_launch}
     pmc = load_pmc(key)
     if pmc and pmc.get("batch") == batch:
         per = pmc["per_env_step"]
         if "hbm_bytes" in per:
             rl["traffic"] = per["hbm_bytes"] * env_steps_per_launch
             rl["hbm_measured_GBps"] = per["hbm_bytes"] * rate / 1e9
-            rl["traffic_source"] = pmc.get("source")
         if "SQ_INSTS_VALU" in per:
             ginst = per["SQ_INSTS_VALU"] * rate / 64.0 / 1e9 if pmc.get("insts_are_per_lane") else per["SQ_INSTS_VALU"] * rate / 1e9
             rl["valu_issue"] = {"bound": "valu_issue", "valu_insts_per_env_step": per["SQ_INSTS_VALU"],
                                 "salu_insts_per_env_step": per.get("SQ_INSTS_SALU"), "lds_insts_per_env_step": per.get("SQ_INSTS_LDS"),
                                 "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
                                 "frac": ginst / VALU_PEAK_GINST, "valu_busy": pmc.get("valu_busy"),
-                                "waves_per_simd": pmc.get("waves_per_simd"), "source": pmc.get("source"),
-                                "peak_note": "256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave-instruction"}
+                                "waves_per_simd": pmc.get("waves_per_simd"), "source": pmc.get("source")}
     return rl
 
 
@@ -224,10 +225,15 @@ def phy_record(clock, args, variant):
     topo = load_topology("us14_3-paths_6-modulations")
     pairs, mod, gsnr = load_phy_tables("us14_k3")
     defrag = variant == "phy_defrag"
-    metrics = variant in ("phy_metrics", "phy_defrag")
+    gn = variant == "phy_gn"
+    metrics = variant in ("phy_metrics", "phy_defrag", "phy_gn")
+    gate = None
+    if gn:   # configs[2] as BASELINE words it: the GN-model OSNR gate of the chosen channels inside the step
+        from optical_rl_gym_amd import gn_gate_parameters
+        gate = gn_gate_parameters(topo)
     env = BatchedPhyRMSAEnv(topo, B, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=1400,
                             mean_service_holding_time=25, episode_length=200, seed=10, grooming=False,
-                            defrag_period=10 if defrag else None, number_moves=10 if defrag else None, metric="cut")
+                            defrag_period=10 if defrag else None, number_moves=10 if defrag else None, metric="cut", gn_gate=gate)
     env.set_stream(clock.stream.cuda_stream)
     out = None
     if metrics:   # the reference's step() computes both every step (phy_rmsa_env.py:319-348): written to device buffers
@@ -246,6 +252,20 @@ def phy_record(clock, args, variant):
     elapsed, kms = clock.timed(launch, steps)
     red, _ = env.reduce_counters()
     kernel = env.last_kernel()
+    gn_info = None
+    if gn:
+        # what the gate costs per env-step, from one more launch with outputs: a check = one chosen channel against the live
+        # occupancy (2 asinh per other channel, evaluated for the W x 64 channel lanes, + 1; 2 exp per hop of the path)
+        tr = env.run("bmfa", chunk, auto_reset=True, outputs=("act_path", "n_channels", "accepted", "gn_gsnr_db"))
+        checked = ~np.isnan(tr["gn_gsnr_db"])
+        nch = tr["n_channels"].astype(np.int64)
+        checks = float(np.where(checked, np.where(tr["accepted"] != 0, nch, 1), 0).sum()) / checked.size
+        hbar = float(np.mean(topo.path_hops))
+        gn_info = {"steps_with_a_check": float(checked.mean()), "gate_rejections_per_env_step": float((checked & (tr["accepted"] == 0)).mean()),
+                   "checks_per_env_step_at_least": checks, "asinh_per_check": 2 * 267 + 1, "exp_per_check_mean": 2 * hbar,
+                   "asinh_per_env_step_at_least": checks * (2 * 267 + 1), "exp_per_env_step_at_least": checks * 2 * hbar,
+                   "bound": "fp64 transcendental / VALU issue (see roofline.valu_issue)", "parity": "unpinned by the reference "
+                   "(it gates by table only: phy_rmsa_env.py:596); pinned to the oracle's restatement of examples/calculate_osnr.py:9-56"}
     st = env.episode_stats()
     running = float(env.num_running().mean())
     env.close()
@@ -254,10 +274,13 @@ def phy_record(clock, args, variant):
     rec = {"value": B * chunk * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": chunk,
            "launches_timed": steps, "timed_region_s": elapsed, "ms_per_launch": elapsed * 1e3 / steps,
            "policy": "bmfa (cut metric)", "per_step_metrics": metrics, "defragmentation": "period 10, 10 moves, cut" if defrag else None,
+           "gn_gate": None,
            "step_kernel": kernel.split(" ")[0], "launch": kernel, "mean_running_services": running,
            "queue_overflow": int(st["queue_overflow"].max()),
            "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),
            "roofline": roofline_block(variant, kernel.split(" ")[0], kernel_ms, A, B * chunk, B)}
+    if gn_info:
+        rec["gn_gate"] = gn_info
     return rec
 
 
@@ -371,9 +394,21 @@ def cpu_baseline(topo, seconds=10.0):
             "value_1core": one[0][0] / one[0][1],
             "sample": f"{cores} threads x 1 env each, {total} steps in {wall:.1f} s (+ {one[0][0]} steps on one thread), SAP-FF, "
                       "same NSFNET-320 load-50 workload, oracle/orlg_oracle.c",
-            "note": "the C oracle is the only CPU restatement timed here: a NumPy restatement of this per-request algorithm is "
-                    "slower than the C one by construction (the reference itself, Python + NumPy, runs 242 env-steps/s on one "
-                    "core: BASELINE.md section 2; it cannot travel to the GPU box)"}
+            "note": "C oracle only; the reference (Python + NumPy) runs 242 env-steps/s on one core (BASELINE.md 2) and cannot travel"}
+
+
+def compact(x, keep=("value", "ms_per_step", "timed_region_s")):
+    """Floats to 6 significant digits (the headline's value / ms_per_step / timed_region_s stay as measured) and no null
+    entries below the top level: the whole line, every sub-record included, has to fit the tail the driver keeps."""
+    def walk(v, top):
+        if isinstance(v, dict):
+            return {k: (vv if (top and k in keep) else walk(vv, False)) for k, vv in v.items() if top or vv is not None}
+        if isinstance(v, (list, tuple)):
+            return [walk(e, False) for e in v]
+        if isinstance(v, float):
+            return float("%.6g" % v)
+        return v
+    return walk(x, True)
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -393,9 +428,10 @@ def main():
 
     import numpy as np
     import torch
-    if world > 1:
+    if world_env is not None:   # launched as a rank (also WORLD_SIZE=1: the RCCL leg then runs with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -421,6 +457,10 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        collective = None
+        if dist is not None:   # what the collective did, for the one-rank test of the RCCL leg (tests/test_gpu_distributed.py)
+            collective = {"backend": dist.get_backend(), "world": world, "local_stats": [int(x) for x in vec],
+                          "reduced_stats": [int(x) for x in stats], "clock_local_s": elapsed, "clock_max_s": float(tmax.item())}
         elapsed = float(tmax.item())
         total_steps = B * world * args.chunk * args.steps
         out = {
@@ -443,12 +483,14 @@ def main():
                        "env_steps_per_launch_per_env": args.chunk, "parallelism": f"env-shard x{world}"},
             "timed_region_s": elapsed,
             "step_kernel": rec["step_kernel"], "launch": rec["launch"],
-            "roofline": rec["roofline"],
+            "roofline": rec["roofline"], "roofline_note": ROOFLINE_NOTE,
             "blocking": {"services_processed": int(stats[0]), "services_accepted": int(stats[1]),
                          "service_blocking_rate": float((stats[0] - stats[1]) / max(1, stats[0])),
                          "bit_rate_blocking_rate": float((stats[4] - stats[5]) / max(1, stats[4])),
                          "episodes_done": int(stats[8]), "num_envs": int(stats[9])},
         }
+        if collective is not None and args.no_sub_records:
+            out["collective"] = collective
         if elapsed < 1.0:
             out["timed_region_short"] = "timed region below 1 s: raise --steps"
     if rank == 0 and world == 1 and not args.no_sub_records:
@@ -456,6 +498,7 @@ def main():
                 "phy_metrics": lambda: phy_record(clock, args, "phy_metrics"),
                 "phy": lambda: phy_record(clock, args, "phy"),
                 "phy_defrag": lambda: phy_record(clock, args, "phy_defrag"),
+                "phy_gn": lambda: phy_record(clock, args, "phy_gn"),
                 "deeprmsa": lambda: deeprmsa_record(clock, args)}
         for name, job in jobs.items():
             if only is None and name == "rmsa_b4096" and args.batch == 4096:
@@ -468,12 +511,13 @@ def main():
         if sub:
             names = {"rmsa_b4096": "rmsa_b4096 (BASELINE configs[1])", "phy_metrics": "phy_us14_b4096 (BASELINE configs[2], with per-step metrics)",
                      "phy": "phy_us14_b4096_lazy_metrics", "phy_defrag": "phy_us14_b4096_defragmentation",
+                     "phy_gn": "phy_us14_b4096_gn_gate (BASELINE configs[2] as worded)",
                      "deeprmsa": "deeprmsa_b32768 (BASELINE configs[3])"}
             out["sub_records"] = {names[k]: v for k, v in sub.items()}
         if world == 1 and not args.no_cpu_baseline and only is None:
             from conftest import load_topology
             out["cpu_baseline"] = cpu_baseline(load_topology(TOPOLOGY))
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact(out)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

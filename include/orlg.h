@@ -35,7 +35,8 @@ enum {
     ORLG_ERR_QUEUE_FULL = -4,  /* an environment's release queue (PhyRMSA: also a channel_state list or the defragmentation
                                 * work list) overflowed: the simulation of that environment is no longer the reference's.
                                 * Sticky: reported by every orlg_step / orlg_synchronize / orlg_reduce_counters that waits
-                                * for the stream after the launch that overflowed, until a full reset.  Raise queue_capacity. */
+                                * for the stream after the launch that overflowed, until a full reset or the load of a
+                                * checkpoint taken before the overflow.  Raise queue_capacity. */
 };
 
 /* Frozen topology: topology.graph["ksp"|"k_paths"|"node_indices"] + edge attr "index"
@@ -206,7 +207,9 @@ int orlg_simple_matrix_obs_dim(orlg_env *env);
 
 /* checkpoint / resume (the reference has none for environment state): the complete simulation state
  * of the handle -- occupancy, release queue, RNG, pending requests, counters, statistics -- as one flat blob of
- * orlg_state_size() bytes (host or device buffer).  A blob only fits a handle created with the same arguments. */
+ * orlg_state_size() bytes (host or device buffer).  A blob only fits a handle created with the same arguments.
+ * orlg_load_state recomputes the sticky error word from the loaded state: a clean checkpoint clears a reported
+ * ORLG_ERR_QUEUE_FULL, the checkpoint of an overflowed batch reports it again. */
 int64_t orlg_state_size(orlg_env *env);
 int orlg_save_state(orlg_env *env, void *buffer);
 int orlg_load_state(orlg_env *env, const void *buffer);

@@ -233,6 +233,13 @@ __global__ void orlg_overflow_kernel(const OrlgEnvScalars *scal, int B, int *out
     if (any) atomicOr(out, 1);
 }
 
+// the sticky error word (mapped host memory: a plain store, no atomic across the bus) recomputed from the scalars
+__global__ void orlg_overflow_store_kernel(const OrlgEnvScalars *scal, int B, int *err_flag) {
+    int any = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) any |= scal[i].q_overflow;
+    if (any) *err_flag = 1;
+}
+
 // ---------------------------------------------------------------------------------------- kernel dispatch
 // the kernels live in per-W objects (orlg_inst_wave.hip / orlg_inst_group.hip); a W the library was not built for is a null symbol
 typedef orlg_rmsa_kernel_t rmsa_kernel_t;
@@ -994,7 +1001,15 @@ int orlg_save_state(orlg_env *e, void *buffer) {
 }
 int orlg_load_state(orlg_env *e, const void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return orlg_state_copy(rmsa_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    int rc = orlg_state_copy(rmsa_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    if (rc) return rc;
+    // the sticky error word describes the state the handle holds: recomputed from the loaded scalars (a clean checkpoint
+    // clears a reported ORLG_ERR_QUEUE_FULL, a checkpoint of an overflowed batch brings it back)
+    *e->err.host = 0;
+    hipLaunchKernelGGL(orlg_overflow_store_kernel, dim3(64), dim3(256), 0, e->stream, e->p.scal, e->p.B, e->err.dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
 }
 }
 

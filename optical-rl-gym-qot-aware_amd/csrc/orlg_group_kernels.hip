@@ -335,6 +335,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     // only the live part of the ring moves between HBM and LDS (a launch of one step would otherwise spend most of its
     // traffic on empty slots); LDS slots outside it are never read
     const int q_head0 = q_head;
+    int q_pops = 0;   // releases of this launch: the head may lap the ring (a 1000-step launch pops ~8 x Q entries)
     if constexpr (HBMQ) {
         qtime = p.qtime + (size_t)env * Q;
         qdesc = p.qdesc + (size_t)env * Q;
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 if (rel_now) {
                     if (gl == 0) { qtime[q_head] = INF; qdesc[q_head] = 0u; }
                     q_head = q_head + 1 == Q ? 0 : q_head + 1;
+                    q_pops += 1;
                     q_n -= 1;
                     n_running -= 1;
                     sum_bitrate_running -= tb.bit_rates[bri2];
@@ -688,12 +690,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     }
     if (act) {
         if constexpr (!HBMQ) {
-            // the ring from where its head was at the start (slots popped since then hold (+inf, 0)) to its last entry
+            // the ring from where its head was at the start (slots popped since then hold (+inf, 0)) to its last entry; the
+            // number of pops, not the head's distance modulo Q, says how far that is: a head that went round the ring has
+            // emptied slots beyond (q_head - q_head0) % Q + q_n whose old entries HBM would otherwise keep
             double *gqt = p.qtime + (size_t)env * Q;
             uint32_t *gqd = p.qdesc + (size_t)env * Q;
-            int span = q_head - q_head0;
-            span += span < 0 ? Q : 0;
-            span += q_n;
+            int span = q_pops + q_n;
             span = span > Q ? Q : span;
             for (int j = gl; j < span; j += ORLG_GL) {
                 int pos = q_head0 + j;

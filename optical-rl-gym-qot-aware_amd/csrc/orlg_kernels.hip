@@ -893,7 +893,8 @@ DEV void rmsa_body(const OrlgParams &p) {
     int mt_idx = gs->mt_idx, new_service = gs->new_service;
     // release queue: a time-sorted ring in LDS -- q_n entries from slot q_head on, ascending release time (OrlgParams::qtime)
     int q_head = gs->q_head, q_n = gs->n_running < Q ? gs->n_running : Q;   // (n_running also counts services an overflow lost)
-    double next_rel = readlane_d(wv.qtime[q_head], 0);   // release time at the ring's head, +inf when the queue is empty
+    // release time at the ring's head; an empty ring's slots hold +inf, but a state from elsewhere (load_state) is not trusted on it
+    double next_rel = q_n > 0 ? readlane_d(wv.qtime[q_head], 0) : __longlong_as_double((long long)ORLG_INF_BITS);
     int eproc = (int)gs->c[2];  // episode_services_processed, mirrored in a register for `done`
     if (lane < 8) wv.wsc->c[lane] = gs->c[lane];
     if (lane == 0) {
@@ -1192,7 +1193,7 @@ DEV void rmsa_body(const OrlgParams &p) {
                 q_head = q_head + 1 == Q ? 0 : q_head + 1;
                 q_n -= 1;
                 apply_window<W>(wv, rec->link, hops, s0, n, true);   // (ends with a wave_sync)
-                next_rel = readlane_d(wv.qtime[q_head], 0);          // the next entry, +inf when none is left
+                next_rel = q_n > 0 ? readlane_d(wv.qtime[q_head], 0) : __longlong_as_double((long long)ORLG_INF_BITS);   // the next entry
                 sum_sh -= n * hops;
                 SEC(11);  // statistics at release
                 if (NET)

@@ -5,7 +5,8 @@
 
 struct orlg_phy_env {
     OrlgPhyParams p;
-    int W, device, waves_per_block, num_paths, resident_blocks;
+    int W, device, waves_per_block, num_paths, num_cu;
+    int resident_blocks[32];   // per kernel variant (phy_launch)
     uint32_t ticket_base;
     hipStream_t stream;
     bool own_stream;
@@ -109,24 +110,37 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
     if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x < 11 ? part[0][threadIdx.x] : 0;
 }
 
+// the sticky error word recomputed from the scalars (orlg_phy_load_state; mapped host memory: a plain store)
+__global__ void orlg_phy_overflow_store_kernel(const OrlgPhyScalars *scal, int B, int *err_flag) {
+    int any = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) any |= scal[i].q_overflow;
+    if (any) *err_flag = 1;
+}
+
 static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
-    // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation, 2 + GN-model admission check
-    const int df = p.gn_on ? 2 : p.defrag_period > 0 ? 1 : 0;
+    // kernel variant (orlg_inst_phy.hip): 0 the step proper, 1 + periodic defragmentation, 2 + defragmentation and GN-model
+    // admission check, 3 + GN-model admission check alone
+    const int df = p.gn_on ? (p.defrag_period > 0 ? 2 : 3) : p.defrag_period > 0 ? 1 : 0;
     const int pol = p.mode == ORLG_MODE_STEP ? p.policy : ORLG_PHY_POLICY_EXTERNAL;   // one instantiation per policy
-    phy_kernel_t k = pick_phy(e->W, df + 3 * (pol + 1));
+    const int variant = df + 4 * (pol + 1);
+    phy_kernel_t k = pick_phy(e->W, variant);
     if (!k) return fail(ORLG_ERR_INVALID, "no PhyRMSA kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
     const int wpb = e->waves_per_block;
-    if (e->resident_blocks <= 0) {
+    // the instantiations differ in registers and scratch: the resident workgroups (= the grid of the work queue) per variant
+    if (e->resident_blocks[variant] <= 0) {
         int nb = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+        if (e->num_cu <= 0) {
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+            e->num_cu = prop.multiProcessorCount;
+        }
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), ORLG_WAVE * wpb, e->lds_block_bytes));
-        e->resident_blocks = (nb > 0 ? nb : 1) * prop.multiProcessorCount;
+        e->resident_blocks[variant] = (nb > 0 ? nb : 1) * e->num_cu;
     }
     int nblocks = (p.B + wpb - 1) / wpb;
-    if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
+    if (nblocks > e->resident_blocks[variant]) nblocks = e->resident_blocks[variant];
     OrlgPhyParams q = p;
     // the node-degree vectors are rebuilt from the occupancy by every launch that evaluates the cut metric, and only by those
     q.use_nv = (p.use_nv && p.mode == ORLG_MODE_STEP &&
@@ -139,7 +153,7 @@ static int phy_launch(orlg_phy_env *e, const OrlgPhyParams &p) {
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_phy_kernel<%d,%s,%d> grid=%d block=%d lds=%zu", e->W,
-             df == 2 ? "true,true" : df == 1 ? "true,false" : "false,false", pol, nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
+             df == 2 ? "true,true" : df == 1 ? "true,false" : df == 3 ? "false,true" : "false,false", pol, nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 
@@ -215,7 +229,7 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
     e->W = W; e->device = device; e->own_stream = true; e->staging = nullptr; e->staging_bytes = 0;
     e->d_act_path = nullptr; e->d_act_ch = nullptr; e->num_paths = t->num_paths;
     e->err.host = nullptr; e->err.dev = nullptr; e->last_kernel[0] = 0;
-    e->resident_blocks = 0; e->ticket_base = 0;
+    memset(e->resident_blocks, 0, sizeof(e->resident_blocks)); e->num_cu = 0; e->ticket_base = 0;
     for (int i = 0; i < ORLG_PHY_NUM_OUTS; i++) { e->io_buf[i] = nullptr; e->io_cap[i] = 0; }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (he != hipSuccess) { delete e; return fail(ORLG_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(he)); }
@@ -670,7 +684,13 @@ int orlg_phy_save_state(orlg_phy_env *e, void *buffer) {
 }
 int orlg_phy_load_state(orlg_phy_env *e, const void *buffer) {
     if (!e || !buffer) return fail(ORLG_ERR_INVALID, "null argument");
-    return orlg_state_copy(phy_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    int rc = orlg_state_copy(phy_state_parts(e), const_cast<void *>(buffer), false, e->device, e->stream);
+    if (rc) return rc;
+    *e->err.host = 0;   // as orlg_load_state: the error word follows the loaded state
+    hipLaunchKernelGGL(orlg_phy_overflow_store_kernel, dim3(64), dim3(256), 0, e->stream, e->p.scal, e->p.B, e->err.dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
 }
 int orlg_phy_channel_state_capacity(orlg_phy_env *e) { return e ? e->p.cs_len : ORLG_ERR_INVALID; }
 int orlg_phy_get_channel_state(orlg_phy_env *e, int32_t env_index, uint32_t *entries, uint8_t *lengths) {

@@ -21,9 +21,9 @@ def shard_base_seed(base_seed: int, batch_per_rank: int, rank: int) -> int:
 
 def allreduce_stats(vec, dist=None, device=None):
     """Sum the int64 statistics vector (length 16) over all ranks; returns a numpy array.  ``dist`` is the
-    initialised ``torch.distributed`` module (None = single process)."""
+    initialised ``torch.distributed`` module (None = single process; a group of one rank still runs the collective)."""
     vec = np.asarray(vec, dtype=np.int64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return vec.copy()
     import torch
     t = torch.from_numpy(vec.copy())

@@ -206,10 +206,20 @@ class BatchedPhyRMSAEnv:
         if policy == "external":
             if act_path is None or act_channels is None:
                 raise ValueError("policy 'external' needs act_path and act_channels")
+            # host arrays: integers only (as BatchedRMSAEnv.run), and every value must survive the cast to the ABI's types --
+            # a float or an out-of-range entry is refused, not truncated or wrapped
+            def _as(name, a, dt):
+                a = np.asarray(a)
+                if a.dtype.kind not in "iu":
+                    raise TypeError(f"{name} must be an integer array, got {a.dtype}")
+                info = np.iinfo(dt)
+                if a.size and (a.min() < info.min or a.max() > info.max):
+                    raise ValueError(f"{name} has values outside {np.dtype(dt).name}")
+                return np.ascontiguousarray(a, dt)
             if not hasattr(act_path, "data_ptr"):
-                act_path = np.ascontiguousarray(act_path, np.int32)
+                act_path = _as("act_path", act_path, np.int32)
             if not hasattr(act_channels, "data_ptr"):
-                act_channels = np.ascontiguousarray(act_channels, np.int16)
+                act_channels = _as("act_channels", act_channels, np.int16)
             _check_buffer("act_path", act_path, (B,), np.int32)
             _check_buffer("act_channels", act_channels, (B, _lib.PHY_MAX_CHANNELS), np.int16)
             ap, ac = _ptr(act_path), _ptr(act_channels)

@@ -42,6 +42,29 @@ def test_overflow_is_returned_by_step_and_synchronize(nsfnet, kernel):
     env.close()
 
 
+def test_load_state_recomputes_the_error_word(nsfnet):
+    """The sticky ORLG_ERR_QUEUE_FULL describes the state the handle holds: loading a clean checkpoint -- the natural recovery
+    -- clears it, loading the checkpoint of an overflowed batch brings it back (include/orlg.h, orlg_load_state)."""
+    from optical_rl_gym_amd import OrlgError
+    kw = dict(num_spectrum_resources=320, load=150, mean_service_holding_time=25, episode_length=1000, seed=1)
+    env = make_batched(nsfnet, kw, 16, queue_capacity=64)
+    env.run("sap_ff", 5)
+    clean = env.save_state()
+    with pytest.raises(OrlgError):
+        env.run("sap_ff", 3000, outputs=("accepted",))
+    bad = env.save_state()
+    env.load_state(clean)
+    env.synchronize()                                   # no longer reported
+    r = env.run("sap_ff", 5, outputs=("accepted",))     # and the batch steps on from the checkpoint
+    assert r["accepted"].shape == (5, 16)
+    env.reduce_counters()
+    env.load_state(bad)
+    with pytest.raises(OrlgError) as ei:
+        env.synchronize()
+    assert ei.value.code == -4
+    env.close()
+
+
 def test_wrong_action_arrays_are_refused(nsfnet):
     kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=1)
     env = make_batched(nsfnet, kw, 8)
@@ -116,3 +139,25 @@ def test_phy_level_zero_tables_are_refused():
     with pytest.raises(OrlgError) as ei:
         make_env(topo, (pairs, mod, gsnr), meta["env_kwargs"], 2)
     assert ei.value.code == -1 and "modulation level" in str(ei.value)
+
+
+def test_phy_wrong_action_arrays_are_refused():
+    """External (path, channels) actions from host arrays: integers only and inside the ABI's int32 / int16, as
+    BatchedRMSAEnv.run validates its actions -- a float or an out-of-range channel number is refused, not truncated or wrapped."""
+    z, meta = load_golden("phy_us14_s10_sapff")
+    topo, tables = load_topology(meta["topology"]), load_phy_tables(meta["tables"])
+    env = make_env(topo, tables, meta["env_kwargs"], 4)
+    ch = np.full((4, 14), -1, np.int64)
+    with pytest.raises(TypeError):
+        env.run("external", 1, act_path=np.zeros(4, np.float64), act_channels=ch)
+    with pytest.raises(TypeError):
+        env.run("external", 1, act_path=np.zeros(4, np.int32), act_channels=ch.astype(np.float32))
+    big = ch.copy()
+    big[0, 0] = 70000    # would wrap to 4464 as int16
+    with pytest.raises(ValueError):
+        env.run("external", 1, act_path=np.zeros(4, np.int32), act_channels=big)
+    with pytest.raises(ValueError):
+        env.run("external", 1, act_path=np.zeros(3, np.int32), act_channels=ch)
+    r = env.run("external", 1, act_path=np.full(4, -2, np.int64), act_channels=ch, outputs=("accepted",))   # blocked: (-2, [])
+    assert r["accepted"].shape == (1, 4) and not r["accepted"].any()
+    env.close()

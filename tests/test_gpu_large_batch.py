@@ -1,6 +1,6 @@
 """Full-size batches of BASELINE.json on the device, held to the oracle on sampled environments:
 the north-star batch (65 536 environments, four-environments-per-wave kernel picked by AUTO) and the topology groups of
-configs[4] (NSFNET / JPN12 / US14) at 8 192 environments each."""
+configs[4] (NSFNET / JPN12 / US14) at 32 768 environments each, the per-GPU batch of that configuration."""
 import ctypes as C
 
 import numpy as np
@@ -70,16 +70,19 @@ def test_north_star_batch_65536(device_log_in_oracle):
 
 
 @pytest.mark.parametrize("name", ["nsfnet_chen_5-paths_6-modulations", "jpn12_5-paths_6-modulations", "us14_3-paths_6-modulations"])
-def test_mixed_topology_groups_8192(name, device_log_in_oracle):
-    """The three topology groups of BASELINE configs[4] (JPN12 stands in for "JPN48": SURVEY 0.7), 8 192 environments each on
-    the four-environments-per-wave kernel, sampled environments against the oracle."""
+def test_mixed_topology_groups_32768(name, device_log_in_oracle):
+    """The three topology groups of BASELINE configs[4] (JPN12 stands in for "JPN48": SURVEY 0.7) at that configuration's
+    per-GPU batch, 262 144 / 8 = 32 768 environments, on the kernel AUTO picks for it (four environments per wave); sampled
+    environments -- first / last of the batch, of a quad, of the resident set, of the ticket queue -- against the oracle."""
     from optical_rl_gym_amd import BatchedRMSAEnv
     topo = load_topology(name)
     kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=10)
-    B = 8192
-    env = BatchedRMSAEnv(topo, B, step_kernel="group", **kw)
+    B = 32768
+    env = BatchedRMSAEnv(topo, B, **kw)
     env.run("sap_ff", 200)
     tr = env.run("sap_ff", 150, outputs=("act_path", "act_slot", "accepted"))
     assert env.last_kernel().startswith("orlg_rmsa_group_kernel"), env.last_kernel()
-    _check_samples(env, topo, kw, "sap_ff", 200, 150, tr, (0, 3, 4, 4095, 4096, 8190, 8191))
+    _check_samples(env, topo, kw, "sap_ff", 200, 150, tr, (0, 3, 4, 4095, 4096, 11263, 11264, 16384, 20001, 32764, 32767))
+    red, _ = env.reduce_counters()
+    assert red["num_envs"] == B and red["services_processed"] == 351 * B
     env.close()

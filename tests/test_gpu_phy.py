@@ -353,9 +353,12 @@ def test_phy_every_policy_instantiation_vs_oracle(policy, defrag, device_log_in_
     env.close()
 
 
-@pytest.mark.parametrize("policy,launch_power_dbm", [("bmfa", 0.0), ("sapff", 2.0), ("faff", 1.0), ("bmff", 0.0), ("bmfa_rss", 1.0),
-                                                     ("sapbm", 0.0), ("faff_rss", 2.0)])
-def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_oracle):
+@pytest.mark.parametrize("policy,launch_power_dbm,defrag", [("bmfa", 0.0, None), ("sapff", 2.0, None), ("faff", 1.0, None), ("bmff", 0.0, None),
+                                                            ("bmfa_rss", 1.0, None), ("sapbm", 0.0, None), ("faff_rss", 2.0, None),
+                                                            ("bmfa", 0.0, "cut"), ("sapff", 2.0, "rss"), ("faff", 1.0, "cut"),
+                                                            ("bmff", 0.0, "rss"), ("bmfa_rss", 1.0, "rss"), ("sapbm", 0.0, "cut"),
+                                                            ("faff_rss", 2.0, "rss")])
+def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, defrag, device_log_in_oracle):
     """GN-model admission check of the chosen channels inside the QoT-aware step (include/orlg.h orlg_gn_gate).  The reference
     gates by table only: this mode is PARITY UNPINNED by it and pinned to the oracle, which feeds its restatement of
     examples/calculate_osnr.py with the live occupancy.  Decisions, counters and occupancy must agree exactly, the GSNR values
@@ -364,9 +367,12 @@ def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_o
     topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
     gate = gn_gate_parameters(topo, launch_power_dbm=launch_power_dbm)
     kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=10, grooming=False, gn_gate=gate)
-    n, batch = 700, 4
+    if defrag:   # the instantiation that carries both the defragmentation and the gate
+        kw.update(defrag_period=10, number_moves=10, metric=defrag)
+    n, batch = 700 if not defrag else 400, 4
     env = make_env(topo, tables, kw, batch)
-    assert env.last_kernel().startswith("orlg_phy_kernel<5,true,true,"), env.last_kernel()
+    # a handle without defrag_period runs the gate's own instantiation (it does not carry the defragmentation's registers)
+    assert env.last_kernel().startswith("orlg_phy_kernel<5,true,true," if defrag else "orlg_phy_kernel<5,false,true,"), env.last_kernel()
     tr = env.run(policy, n, outputs=("act_path", "channels", "accepted", "gn_gsnr_db", "number_cuts_total"), auto_reset=True)
     cnt, av = env.counters(), env.available_channels()
     gate_blocks = 0
@@ -386,9 +392,53 @@ def test_gn_gate_in_the_step_vs_oracle(policy, launch_power_dbm, device_log_in_o
             assert cnt[name][i] == oc[name], (name, i)
         gate_blocks += int(((ot["act_path"] >= 0) & (ot["act_path"] < 10) & (ot["accepted"] == 0)).sum())
         o.close()
-    assert gate_blocks > 20          # the gate rejects some of the table-approved choices ...
+    assert gate_blocks > (20 if not defrag else 8)   # the gate rejects some of the table-approved choices ...
     assert tr["accepted"].mean() > 0.3  # ... and passes others
     # a virtual-layer service lights nothing new: no check
     virt = tr["act_path"] >= 20
     assert np.all(np.isnan(tr["gn_gsnr_db"][virt]))
+    env.close()
+
+
+def test_gn_gate_batch_4096(device_log_in_oracle):
+    """BASELINE configs[2] as worded -- "QoT-aware RMSA on USNET (GN-model OSNR gate + modulation-format selection), batch =
+    4 096": US14, load 1400, bmfa with the GN-model admission check of the chosen channels inside the step
+    (examples/calculate_osnr.py:9-56 against the live occupancy; PARITY UNPINNED by the reference, which gates by table only:
+    phy_rmsa_env.py:596).  Eight sampled environments -- first / last of the batch, of a workgroup (8 waves), of the resident
+    set -- against the oracle: decisions, occupancy and counters exactly, the GSNR of every check to rtol 1e-9; then the
+    size-independent properties for every environment."""
+    from optical_rl_gym_amd import gn_gate_parameters
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    gate = gn_gate_parameters(topo)
+    kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=10, grooming=False, gn_gate=gate)
+    n, batch = 320, 4096
+    env = make_env(topo, tables, kw, batch)
+    tr = env.run("bmfa", n, outputs=("act_path", "channels", "accepted", "gn_gsnr_db", "number_cuts_total"), auto_reset=True)
+    assert env.last_kernel().startswith("orlg_phy_kernel<5,false,true,"), env.last_kernel()
+    cnt, av = env.counters(), env.available_channels()
+    gate_blocks = 0
+    for i in (0, 7, 8, 2047, 2048, 4088, 4094, 4095):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=10 + i)
+        ot = o.run("bmfa", n, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["accepted"][:, i], ot["accepted"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        g, og = tr["gn_gsnr_db"][:, i], ot["gn_gsnr_db"]
+        assert np.array_equal(np.isnan(g), np.isnan(og)), i
+        np.testing.assert_allclose(g[~np.isnan(g)], og[~np.isnan(og)], rtol=1e-9, atol=0)
+        assert np.array_equal(av[i], o.available_channels()), i
+        oc = o.counters()
+        for name in oc:
+            assert cnt[name][i] == oc[name], (name, i)
+        gate_blocks += int(((ot["act_path"] >= 0) & (ot["act_path"] < 10) & (ot["accepted"] == 0)).sum())
+        o.close()
+    assert gate_blocks > 20
+    assert np.all(cnt["services_processed"] == n + 1)
+    # (accepted of the running episode vs the launch's outputs: an episode of 200 ended inside the launch)
+    checked = ~np.isnan(tr["gn_gsnr_db"])
+    assert checked.mean() > 0.5 and np.all(tr["gn_gsnr_db"][checked] > 0) and np.all(tr["gn_gsnr_db"][checked] < 40)
+    red, _ = env.reduce_counters()
+    assert red["num_envs"] == batch and red["services_processed"] == batch * (n + 1)
+    assert env.episode_stats()["queue_overflow"].max() == 0
     env.close()

@@ -357,6 +357,39 @@ def test_group_kernel_short_launches_keep_the_queue_in_hbm(nsfnet):
     env.close()
 
 
+def test_group_kernel_ring_head_laps_the_queue(nsfnet):
+    """A long launch pops several times the ring's capacity: the head goes round the ring, and the slots it emptied beyond
+    (q_head - q_head0) % Q + q_n must reach HBM as (+inf, 0) too (the group kernel writes back the part of the ring it touched,
+    pops + live entries, not the head's distance modulo Q).  Low load, the smallest queue, 1000-step launches: the saved state
+    equals the wave kernel's byte for byte after every launch, and a state handed from the group kernel to the wave kernel
+    whose queue drains to empty releases nothing that is not there."""
+    kw = dict(num_spectrum_resources=320, load=6, mean_service_holding_time=10, episode_length=500, seed=5, queue_capacity=64)
+    B = 37
+    outs = ("act_path", "act_slot", "accepted", "arrival")
+    a = make_batched(nsfnet, kw, B, step_kernel="wave")
+    b = make_batched(nsfnet, kw, B, step_kernel="group")
+    for n in (1000, 1000, 333, 1000):
+        ta = a.run("sap_ff", n, outputs=outs, auto_reset=True)
+        tb = b.run("sap_ff", n, outputs=outs, auto_reset=True)
+        assert "group_kernel" in b.last_kernel() and ",true>" not in b.last_kernel(), b.last_kernel()   # the ring in LDS
+        for k in outs:
+            assert np.array_equal(ta[k], tb[k]), (n, k)
+        assert np.array_equal(a.save_state(), b.save_state()), n
+    # group -> wave hand-over, then a stretch long enough for every queue to run empty at this load
+    a.load_state(b.save_state())
+    ta = a.run("sap_ff", 400, outputs=outs, auto_reset=True)
+    tb = b.run("sap_ff", 400, outputs=outs, auto_reset=True)
+    for k in outs:
+        assert np.array_equal(ta[k], tb[k]), k
+    ca, cb = a.counters(), b.counters()
+    for name in ca:
+        assert np.array_equal(ca[name], cb[name]), name
+    assert np.array_equal(a.occupancy_words(), b.occupancy_words())
+    assert np.array_equal(a.save_state(), b.save_state())
+    a.close()
+    b.close()
+
+
 def test_kernels_continue_each_other(nsfnet):
     """One state format: a batch stepped by the wave-per-environment kernel is handed (save_state / load_state) to the
     four-environments-per-wave kernel and back; outputs and final state equal an uninterrupted run."""

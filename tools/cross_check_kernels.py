@@ -59,7 +59,7 @@ def main():
         except OrlgError as e:
             skipped += 1
             continue
-        for n in [int(x) for x in rng.choice([1, 2, 7, 40, 150], size=5)]:
+        for n in [int(x) for x in rng.choice([1, 2, 7, 40, 150, 1000], size=5)]:
             for t in range(1 if policy in ("sap_ff", "sp_ff") else n):
                 if policy == "external":
                     act = np.stack([rng.integers(0, k + 1, B), rng.integers(0, S + 1, B)], axis=-1).astype(np.int32)

@@ -4,7 +4,7 @@ and a pmc.json entry; `python tools/profile_bench.py --collect` (build container
 profiles/ (tracked).
 
     python tools/profile_bench.py <name> [--tag r02] [--steps 3] [--quick]
-    name: headline | rmsa_b4096 | phy | phy_metrics | phy_defrag | deeprmsa      (bench.py --only)
+    name: headline | rmsa_b4096 | phy | phy_metrics | phy_defrag | phy_gn | deeprmsa      (bench.py --only)
 
 Passes (separate rocprofv3 invocations, as MI355X_MICROARCH.md prescribes: kernel trace and counters never together,
 FETCH_SIZE and WRITE_SIZE in passes of their own):
@@ -35,6 +35,7 @@ WORK = {
     "phy": ("orlg_phy_kernel", "phy", 4096, 250),
     "phy_metrics": ("orlg_phy_kernel", "phy_metrics", 4096, 250),
     "phy_defrag": ("orlg_phy_kernel", "phy_defrag", 4096, 250),
+    "phy_gn": ("orlg_phy_kernel", "phy_gn", 4096, 250),
     "deeprmsa": ("orlg_rmsa_", "deeprmsa", 32768, 1),
 }
 PMC_PASSES = {
@@ -79,7 +80,7 @@ def main():
         return collect()
     ap = argparse.ArgumentParser()
     ap.add_argument("name", choices=sorted(WORK))
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--quick", action="store_true", help="skip the FETCH_SIZE / WRITE_SIZE passes")
     ap.add_argument("--extra", default="", help="extra bench.py arguments, e.g. '--step-kernel wave'")
