@@ -199,6 +199,10 @@ int orlg_query_path_mask(orlg_env *env, int32_t env_index, int32_t path_gid, uin
 
 /* DeepRMSAEnv.observation() (deeprmsa_env.py:60-121) for every env: [B][1 + 2N + (2j+3)k] float64 */
 int orlg_deeprmsa_observation(orlg_env *env, double *out);
+/* the same vectors as float32 -- every element the float64 value rounded once to nearest, i.e. numpy's
+ * obs.astype(float32), which is what a stable-baselines agent does with the reference's Box(float64) observation: half the
+ * bytes written and, for a host buffer, copied back */
+int orlg_deeprmsa_observation_f32(orlg_env *env, float *out);
 int orlg_deeprmsa_obs_dim(orlg_env *env);
 
 /* SimpleMatrixObservation.observation() (rmsa_env.py:940-971) for every env: [B][2N + E*S] uint8 */

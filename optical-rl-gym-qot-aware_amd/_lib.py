@@ -125,6 +125,7 @@ def load(build_if_missing=True):
     L.orlg_query_path_masks.argtypes = [vp, i32, vp, vp]
     L.orlg_query_path_mask.argtypes = [vp, i32, i32, vp, vp]
     L.orlg_deeprmsa_observation.argtypes = [vp, vp]
+    L.orlg_deeprmsa_observation_f32.argtypes = [vp, vp]
     L.orlg_deeprmsa_obs_dim.argtypes = [vp]
     L.orlg_reduce_counters.argtypes = [vp, vp]
     L.orlg_simple_matrix_observation.argtypes = [vp, vp]
@@ -159,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "orlg_synchronize", "orlg_launch_info", "orlg_last_kernel", "orlg_phy_last_kernel", "orlg_reset", "orlg_step", "orlg_get_requests", "orlg_get_counters",
     "orlg_get_current_time", "orlg_get_occupancy", "orlg_words_per_link", "orlg_get_link_stats",
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
-    "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
+    "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_observation_f32", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
     "orlg_simple_matrix_observation", "orlg_simple_matrix_obs_dim", "orlg_host_log",
     "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_node_vectors", "orlg_phy_get_requests", "orlg_phy_get_counters",

@@ -277,12 +277,18 @@ class BatchedRMSAEnv:
         _lib.check(self.L.orlg_query_path_mask(self.h, int(env_index), int(path_gid), _ptr(m), _ptr(n)))
         return m, int(n[0])
 
-    def observation(self, out=None):
-        """DeepRMSAEnv.observation() for every env: [B, obs_dim] float64."""
+    def observation(self, out=None, dtype=np.float64):
+        """DeepRMSAEnv.observation() for every env: [B, obs_dim] float64 (the reference's Box dtype), or float32 -- the
+        float64 vector rounded once, ``obs.astype(np.float32)`` -- with ``dtype=np.float32`` / a float32 ``out`` buffer."""
         if out is None:
-            out = np.zeros((self.batch_size, self.obs_dim), np.float64)
-        else:
-            _check_buffer("out", out, (self.batch_size, self.obs_dim), np.float64)
+            out = np.zeros((self.batch_size, self.obs_dim), dtype)
+        elif _dtype_name(out) == "float32":
+            dtype = np.float32
+        if np.dtype(dtype) == np.float32:
+            _check_buffer("out", out, (self.batch_size, self.obs_dim), np.float32)
+            _lib.check(self.L.orlg_deeprmsa_observation_f32(self.h, _ptr(out)))
+            return out
+        _check_buffer("out", out, (self.batch_size, self.obs_dim), np.float64)
         _lib.check(self.L.orlg_deeprmsa_observation(self.h, _ptr(out)))
         return out
 

@@ -900,18 +900,19 @@ int orlg_query_path_mask(orlg_env *e, int32_t env_index, int32_t path_gid, uint6
 }
 
 int orlg_deeprmsa_obs_dim(orlg_env *e) { return e ? e->p.obs_dim : ORLG_ERR_INVALID; }
-int orlg_deeprmsa_observation(orlg_env *e, double *out) {
+static int deeprmsa_observation(orlg_env *e, void *out, bool f32) {
     if (!e || !out) return fail(ORLG_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->device));
     OrlgParams p = e->p;
-    size_t bytes = (size_t)p.B * p.obs_dim * 8;
+    size_t bytes = (size_t)p.B * p.obs_dim * (f32 ? 4 : 8);
     const bool dev = orlg_is_device_ptr(out);
+    p.obs_f32 = f32 ? 1 : 0;
     if (!dev) {
         int rc = ensure_staging(e, bytes);
         if (rc) return rc;
         p.o_obs = reinterpret_cast<double *>(e->staging);
     } else {
-        p.o_obs = out;
+        p.o_obs = reinterpret_cast<double *>(out);
     }
     rmsa_kernel_t k = pick_obs(e->W);
     const int wpb = e->waves_per_block;
@@ -926,6 +927,8 @@ int orlg_deeprmsa_observation(orlg_env *e, double *out) {
     if (!dev) return copy_out(e, out, e->staging, bytes);
     return ORLG_OK;
 }
+int orlg_deeprmsa_observation(orlg_env *e, double *out) { return deeprmsa_observation(e, out, false); }
+int orlg_deeprmsa_observation_f32(orlg_env *e, float *out) { return deeprmsa_observation(e, out, true); }
 
 int orlg_simple_matrix_obs_dim(orlg_env *e) { return e ? 2 * e->p.N + e->p.E * e->p.S : ORLG_ERR_INVALID; }
 int orlg_simple_matrix_observation(orlg_env *e, uint8_t *out) {

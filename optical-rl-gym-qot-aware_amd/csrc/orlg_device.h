@@ -83,7 +83,8 @@ struct OrlgParams {
     int32_t *hist;            // [B][4][NBR] requested, provisioned, episode requested, episode provisioned
     double *lstat;            // [B][4][E] utilization, external_fragmentation, compactness, last_update
     int32_t *lint;            // [B][lint_stride] per-link span | gaps << 16 (the cache behind _get_network_compactness)
-    int32_t lint_stride, pad_lint;
+    int32_t lint_stride;
+    int32_t obs_f32;          // orlg_deeprmsa_obs_kernel writes float32 (o_obs then points to floats)
     double *ring_iat, *ring_ht;   // [B][64] pre-generated inter-arrival / holding times (in RNG stream order)
     uint32_t *ring_req;           // [B][64] src | dst << 8 | bit-rate index << 16
     // read-only tables: ONE blob in HBM that every workgroup stages into LDS (byte offsets t_*, 16-B aligned)

@@ -1424,6 +1424,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
         }
         wave_sync();
         double *gout = p.o_obs + (size_t)env * p.obs_dim;
+        float *gout32 = reinterpret_cast<float *>(p.o_obs) + (size_t)env * p.obs_dim;   // (obs_f32: the same vector rounded once)
         const int br_val = tb.bit_rates[br];
         for (int i = lane; i < p.obs_dim; i += 64) {
             // element i = num / den (one division for every kind of element), optionally followed by (q - 4) / 4
@@ -1454,7 +1455,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK) void orlg_deep
             }
             res = num / den;
             if (tail) res = (res - 4) * 0.25;   // (x / 4 is x * 0.25 exactly)
-            gout[i] = fixed ? fixed_val : res;
+            const double val = fixed ? fixed_val : res;
+            if (p.obs_f32) gout32[i] = (float)val; else gout[i] = val;
         }
         wave_sync();
     }

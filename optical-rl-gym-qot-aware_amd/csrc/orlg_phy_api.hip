@@ -110,6 +110,35 @@ __global__ __launch_bounds__(256) void orlg_phy_reduce_kernel(const OrlgPhyScala
     if (threadIdx.x < 16) out[threadIdx.x] = threadIdx.x < 11 ? part[0][threadIdx.x] : 0;
 }
 
+// the tables of gn_gsnr: one thread per (channel, interferer) pair / per link.  The expressions are examples/calculate_osnr.py's
+// (:22-48), as gn_gsnr evaluated them per check until round 3.
+__global__ void orlg_gn_tables_kernel(const OrlgPhyParams p, double *A, double *R, double *L) {
+    const double beta_2 = -21.3e-27, pi = 3.141592653589793;
+    const double bw = p.gn_bw, att = p.gn_att;
+    const double l_eff_a = 1 / (2 * att);
+    const int n = p.C * p.cpad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ch = i / p.cpad, c = i - ch * p.cpad;
+        double a = 0.0, rr = 0.0;
+        if (c < p.C && c != ch) {
+            const double fc = p.gn_cf[ch], sf = p.gn_cf[c];
+            a = asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc + (bw / 2))) -
+                asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc - (bw / 2)));
+            rr = bw / fabs(sf - fc);
+        }
+        A[i] = a; R[i] = rr;
+    }
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < p.E; l += gridDim.x * blockDim.x) {
+        const double len = p.gn_spanlen[l];
+        const double l_eff = (1 - exp(-2 * att * len * 1e3)) / (2 * att);
+        L[4 * l] = l_eff;
+        L[4 * l + 1] = l_eff / (len * 1e3);
+        L[4 * l + 2] = exp(2 * att * len * 1e3) - 1;
+        L[4 * l + 3] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) L[4 * p.E] = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4 * att));
+}
+
 // the sticky error word recomputed from the scalars (orlg_phy_load_state; mapped host memory: a plain store)
 __global__ void orlg_phy_overflow_store_kernel(const OrlgPhyScalars *scal, int B, int *err_flag) {
     int any = 0;
@@ -401,6 +430,21 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         HIP_TRY(hipMemcpy(d_m, mt.data(), mt.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_g, gt.data(), gt.size() * 8, hipMemcpyHostToDevice));
         p.mod_t = d_m; p.gsnr_t = d_g;
+        if (p.defrag_period > 0) {
+            // defragmentation rounds: the channels of one modulation level on a (table row, k-path) as W 64-bit masks -- "a free
+            // channel of the candidate's level" (phy_rmsa_env.py:395) is then the path's free word AND one mask word
+            std::vector<uint64_t> lm((size_t)c->num_table_rows * K * 32 * W, 0ull);
+            for (int r = 0; r < c->num_table_rows; r++)
+                for (int k = 0; k < K; k++)
+                    for (int ch = 0; ch < C; ch++) {
+                        const int lv = mt[((size_t)r * K + k) * p.cpad + ch] & 31;
+                        lm[(((size_t)r * K + k) * 32 + lv) * W + (ch >> 6)] |= 1ull << (ch & 63);
+                    }
+            uint64_t *d_lm;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_lm), lm.size() * 8)); e->bufs.push_back(d_lm);
+            HIP_TRY(hipMemcpy(d_lm, lm.data(), lm.size() * 8, hipMemcpyHostToDevice));
+            p.lvl_mask = d_lm;
+        }
         // the levels of one channel on all K paths next to each other (8 bytes per channel): one load per channel and step
         std::vector<uint8_t> mk((size_t)c->num_table_rows * p.cpad * 8, 0);
         for (int r = 0; r < c->num_table_rows; r++)
@@ -498,6 +542,16 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.gn_on = 1; p.gn_nthr = g->num_thresholds;
         p.gn_pw = g->launch_power_w; p.gn_bw = g->channel_bandwidth_hz; p.gn_att = g->attenuation_normalized; p.gn_nf = g->noise_figure;
         p.gn_cf = d_cf; p.gn_nspans = d_ns; p.gn_spanlen = d_sl; p.gn_thr = d_thr;
+        // the table-only part of a check (two asinh per channel pair, two exp per link), evaluated once on the device
+        double *d_A = nullptr, *d_R = nullptr, *d_L = nullptr;
+        TRY(alloc(reinterpret_cast<void **>(&d_A), (size_t)C * p.cpad * 8));
+        TRY(alloc(reinterpret_cast<void **>(&d_R), (size_t)C * p.cpad * 8));
+        TRY(alloc(reinterpret_cast<void **>(&d_L), (size_t)(4 * E + 4) * 8));
+        hipLaunchKernelGGL(orlg_gn_tables_kernel, dim3(256), dim3(256), 0, e->stream, p, d_A, d_R, d_L);
+        er = hipGetLastError();
+        if (er == hipSuccess) er = hipStreamSynchronize(e->stream);
+        if (er != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "GN gate tables: %s", hipGetErrorString(er)); }
+        p.gn_A = d_A; p.gn_R = d_R; p.gn_link = d_L;
     }
     if (p.use_masks) TRY(alloc(reinterpret_cast<void **>(&p.cterm), (size_t)batch * p.cpad * sizeof(double)));   // (scratch, see OrlgPhyParams)
     if (p.defrag_period > 0) {
@@ -505,6 +559,13 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;
         if (Q > 65535) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "defragmentation needs queue_capacity < 65536"); }
         TRY(alloc(reinterpret_cast<void **>(&p.cand), (size_t)batch * p.cand_cap * sizeof(OrlgPhyCand)));
+        // side arrays of the service records (the scans of the defragmentation walk these): part of the state
+        if (t->num_paths >= 16384) { orlg_phy_destroy(e); return fail(ORLG_ERR_INVALID, "defragmentation needs fewer than 16384 path records"); }
+        TRY(alloc(reinterpret_cast<void **>(&p.qsum), (size_t)batch * Q * sizeof(uint64_t)));
+        TRY(alloc(reinterpret_cast<void **>(&p.qseq), (size_t)batch * Q * sizeof(uint32_t)));
+        hipError_t em = hipMemset(p.qsum, 0, (size_t)batch * Q * sizeof(uint64_t));
+        if (em == hipSuccess) em = hipMemset(p.qseq, 0, (size_t)batch * Q * sizeof(uint32_t));
+        if (em != hipSuccess) { orlg_phy_destroy(e); return fail(ORLG_ERR_HIP, "hipMemset: %s", hipGetErrorString(em)); }
     }
     {
         std::vector<uint32_t> mt((size_t)batch * ORLG_MT_N);
@@ -668,9 +729,11 @@ typedef OrlgStatePart StatePart;
 static std::vector<StatePart> phy_state_parts(orlg_phy_env *e) {
     const OrlgPhyParams &p = e->p;
     const size_t B = p.B, lists = (size_t)p.N * p.N * p.K;
-    return {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
+    std::vector<StatePart> parts = {{p.occ, B * p.NW * 8}, {p.qtime, B * p.Q * 8}, {p.qrec, B * p.Q * sizeof(OrlgPhySvc)}, {p.mt, B * ORLG_MT_N * 4},
             {p.scal, B * sizeof(OrlgPhyScalars)}, {p.cs, B * lists * p.cs_len * 4}, {p.cs_n, B * lists},
             {p.ring_iat, B * ORLG_RING * 8}, {p.ring_ht, B * ORLG_RING * 8}, {p.ring_req, B * ORLG_RING * 4}};
+    if (p.qsum) { parts.push_back({p.qsum, B * p.Q * sizeof(uint64_t)}); parts.push_back({p.qseq, B * p.Q * sizeof(uint32_t)}); }
+    return parts;
 }
 int64_t orlg_phy_state_size(orlg_phy_env *e) {
     if (!e) return fail(ORLG_ERR_INVALID, "null handle");

@@ -43,6 +43,16 @@ DEV int cs_used(uint32_t e) { return (int)((e >> 9) & 0x1fu); }
 DEV int cs_free(uint32_t e) { return (int)((e >> 14) & 0x1fu); }
 DEV int cs_cap(uint32_t e) { return (int)((e >> 19) & 0x1fu); }
 static_assert(sizeof(OrlgPhySvc) == 48, "OrlgPhySvc layout");
+// the head of a record in one 64-bit word (OrlgPhyParams::qsum): path, flags, channel count and the first two entries of
+// service.channels (channel | used << 9 | partial << 14: 15 bits each; a service has 1.4 channels on average, the others are read
+// from the record when nch > 2)
+DEV u64 svc_summary(int gid, int flags, int nch, uint32_t hw0, uint32_t hw1) {
+    return (u64)(uint32_t)gid | ((u64)(uint32_t)flags << 14) | ((u64)(uint32_t)nch << 16) | ((u64)(hw0 & 0x7fffu) << 20) | ((u64)(hw1 & 0x7fffu) << 35);
+}
+DEV int sum_gid(u64 s) { return (int)(s & 0x3fffu); }
+DEV int sum_flags(u64 s) { return (int)((s >> 14) & 3u); }
+DEV int sum_nch(u64 s) { return (int)((s >> 16) & 15u); }
+DEV int sum_ch(u64 s, int j) { return (int)((s >> (20 + 15 * j)) & 0x7fffu); }   // j = 0, 1
 
 // per-env scalars in HBM (256 B)
 struct __attribute__((aligned(16))) OrlgPhyScalars {
@@ -80,6 +90,11 @@ struct OrlgPhyParams {
     uint32_t *cs;           // [B][N*N*K][cs_len] channel_state lists (virtual layer), list order = array order
     uint8_t *cs_n;          // [B][N*N*K] list lengths
     OrlgPhyCand *cand;      // [B][cand_cap] defragmentation work list (only with defrag_period > 0)
+    // side arrays of the service records for the periodic defragmentation (only with defrag_period > 0, kept by the DF
+    // instantiations at every site that writes a record): its scans walk 8 + 4 bytes per running service instead of 48
+    uint64_t *qsum;         // [B][Q] svc_summary: gid | flags << 14 | nch << 16 | ch[0] << 20 | ch[1] << 35 (15-bit channel entries)
+    uint32_t *qseq;         // [B][Q] the record's seq (list order of topology.graph["running_services"])
+    const uint64_t *lvl_mask;   // [num_rows*K][32][W] channels of one modulation level on (table row, k-path), as bit masks
     uint32_t *ticket;       // work queue counter; environment = ticket - ticket_base
     uint32_t ticket_base, ticket_stride;
     // shared tables
@@ -100,6 +115,11 @@ struct OrlgPhyParams {
     const int32_t *gn_nspans;   // [E]
     const double *gn_spanlen;   // [E] km
     const double *gn_thr;       // [gn_nthr] dB, ascending
+    // what the check evaluates that depends on the tables only, built once per handle ON THE DEVICE by orlg_gn_tables_kernel
+    // with the very expressions gn_gsnr used to evaluate per check (same compiler, same libm routines: the same bits)
+    const double *gn_A;         // [C][cpad] asinh(k (f_c - f_ch + bw/2)) - asinh(k (f_c - f_ch - bw/2)), 0 on the diagonal
+    const double *gn_R;         // [C][cpad] bw / |f_c - f_ch|, 0 on the diagonal
+    const double *gn_link;      // [E][4] l_eff, l_eff / span length, exp(2 att len) - 1, -; then [4E] = the self-channel asinh term
     double *cterm;          // [B][cpad] scratch: per-channel term of calculate_total_r_spatial while a launch keeps the per-step
                             // totals incrementally (not part of the state: rebuilt at the start of every launch that needs it)
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
@@ -699,11 +719,10 @@ DEV double lane_rss_delta(const u64 *occ, const double *sqrt_tab, const OrlgPath
     return ORLG_FDIV(sqrt_tab[sq1], (double)(sm1 + 1)) - ORLG_FDIV(sqrt_tab[sq0], (double)(sm0 + 1));
 }
 
-// smallest of the lanes' 32-bit keys (exact as doubles); lanes without a key pass has = false; returns -1.0 when no lane has one
+// smallest of the lanes' keys (sequence numbers: below 2^31); lanes without a key pass has = false; returns -1.0 when no lane has one
 DEV double wave_min_key(uint32_t key, bool has) {
-    const double none = 1e18;
-    const double m = -wave_max_f64(has ? -(double)key : -none);
-    return m >= none ? -1.0 : m;
+    const int m = wave_min_i32(has ? (int)key : 0x7fffffff);
+    return m == 0x7fffffff ? -1.0 : (double)m;
 }
 
 // ---- per-step totals kept incrementally (networks of at most 32 links).  _calculate_total_cuts (phy_rmsa_env.py:1195-1203)
@@ -744,29 +763,6 @@ DEV void mc_after(const u64 *occ, MetricCache &mc, int ch, int lane) {
     }
 }
 
-// The two scans of the defragmentation walk all running services, 48-byte records in HBM, through an LDS staging area (a
-// chunk of records, coalesced 16-byte loads, then one record per lane).  The next chunk is requested into registers before
-// the current one is worked on, so that the scan does not wait for HBM once per chunk.
-struct SvcPrefetch { uint4 v[3]; };
-DEV void svc_fetch(SvcPrefetch &pf, const OrlgPhySvc *grec, int i0, int n_running, int chunk, int lane) {
-    const int cnt = n_running - i0 < chunk ? n_running - i0 : chunk;
-    const uint4 *src = reinterpret_cast<const uint4 *>(grec + i0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int q = lane + 64 * k;
-        pf.v[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (q < cnt * 3) pf.v[k] = src[q];
-    }
-}
-DEV void svc_stash(const SvcPrefetch &pf, OrlgPhySvc *stage, int cnt, int lane) {
-    uint4 *dst = reinterpret_cast<uint4 *>(stage);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int q = lane + 64 * k;
-        if (q < cnt * 3) dst[q] = pf.v[k];
-    }
-}
-
 // The periodic defragmentation of PhyRMSAEnv.step (phy_rmsa_env.py:355-417), run when services_processed is a multiple of
 // defrag_period, right after _next_service.  Two passes:
 //  1. _groom_defragmentation (:703-733): a service that is the ONLY user of a partially used channel moves that share
@@ -780,107 +776,220 @@ DEV void svc_stash(const SvcPrefetch &pf, OrlgPhySvc *stage, int cnt, int lane) 
 //     (metric gain, age); in (gain, age) order each candidate looks for a free channel of the same modulation level on
 //     its path and moves there (_move, :662-697) when placing costs less than releasing gains.
 template <int W>
-DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, uint32_t *gcs,
+DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ, PhyWaveScalars *ws, OrlgPhySvc *grec, u64 *gsum,
+                             uint32_t *gseq, uint32_t *gcs,
                              uint8_t *gcs_n, OrlgPhyCand *cand, int *lch /* LDS [16] */, double *r0w /* LDS [W][64] */, int n_running,
                              int &next_seq, double current_time, int req_src, int req_dst, int lane, u64 *gnv, MetricCache &mc SEC_PARAMS) {
     const int N = p.N, K = p.K, E = p.E;
     const bool rss = p.defrag_metric != 0;
     bool overflow = false;
-    // the two scans over all running services read the 48-byte records through LDS: a chunk of records is fetched with
-    // coalesced 16-byte loads into the (otherwise idle) per-channel scratch area, then every lane takes its own record
-    constexpr int CHUNK = (W * 64 * 8) / (int)sizeof(OrlgPhySvc) < 64 ? (W * 64 * 8) / (int)sizeof(OrlgPhySvc) : 64;
-    OrlgPhySvc *stage = reinterpret_cast<OrlgPhySvc *>(r0w);
     // ------------------------------------------------------------------ 1. grooming pass
+    // Which services can the walk act on?  A service whose partially used channel has no other user (the list entry's `used` is
+    // its own share) and whose channel_state list holds another entry with enough residual capacity.  Both are properties of the
+    // LIST: (a) one pass over the lists of the environment (lane = list, coalesced) flags every entry (key, channel, used) that
+    // has such a target in a small Bloom bitmap in LDS; (b) one pass over the 8-byte record summaries (lane = service) tests the
+    // service's partial channels against the bitmap -- no gather per service; (c) the few that pass are resolved exactly against
+    // their list (lane = service again).  The walk of round 2 read every 48-byte record and, per service with a partial channel
+    // (three in four), its list: 190 KB per cycle where this reads 30.
     int n_el = 0;
-    static_assert(CHUNK * 3 <= 192, "three 16-byte rows per lane");
-    SvcPrefetch pf;
-    if (n_running > 0) svc_fetch(pf, grec, 0, n_running, CHUNK, lane);
-    for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
-        const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
-        svc_stash(pf, stage, cnt, lane);
+    {
+        // (the per-channel LDS scratch holds both: W x 512 bytes)
+        constexpr int BM_WORDS = W >= 3 ? 128 : 16 * W;             // 4096 bits (512 / 1024 for one / two words of channels)
+        constexpr int KU = W >= 3 ? 4 : 1;                          // summaries per lane requested at a time
+        uint32_t *bm = reinterpret_cast<uint32_t *>(r0w);
+        uint16_t *maybe = reinterpret_cast<uint16_t *>(bm + BM_WORDS);   // record indices that passed the bitmap
+        constexpr int MAYBE_CAP = (W * 64 * 8 - BM_WORDS * 4) / 2 < 512 ? (W * 64 * 8 - BM_WORDS * 4) / 2 : 512;
+        static_assert(MAYBE_CAP >= 2 * 64 * KU, "room for the services of two rounds that pass the bitmap");
+        for (int q = lane; q < BM_WORDS; q += 64) bm[q] = 0u;
         wave_sync();
-        if (i0 + CHUNK < n_running) svc_fetch(pf, grec, i0 + CHUNK, n_running, CHUNK, lane);   // in flight during this chunk
-        const int idx = i0 + lane;
-        bool elig = false;
-        uint32_t seq = 0;
-        if (lane < cnt) {
-            const OrlgPhySvc *r = stage + lane;
-            const int gid = r->gid, nch = r->nch;
-            seq = r->seq;
-            bool any_partial = false;
-            for (int j = 0; j < nch; ++j) any_partial = any_partial || (r->ch[j] & (1 << 14));
-            if (any_partial) {
-                const int key = svc_key(tb, N, K, gid, r->flags);
-                const uint32_t *lst = gcs + (size_t)key * p.cs_len;
-                // the list's length and its first eight entries are requested together (cs_len is a power of two >= 8): one
-                // HBM round trip for nearly every list
-                const int n = gcs_n[key];
-                const uint4 e03 = reinterpret_cast<const uint4 *>(lst)[0], e47 = reinterpret_cast<const uint4 *>(lst)[1];
+        auto bm_hash = [](int key, int ch, int used) { return (uint32_t)(key * 37 + ch * 11 + used * 1031) & (BM_WORDS * 32 - 1); };
+        // (a) the lists
+        const int n_lists = N * N * K;
+        for (int k0 = 0; k0 < n_lists; k0 += 64) {
+            const int key = k0 + lane;
+            // (length and first eight entries requested together: the entries do not wait for the length)
+            const uint32_t *lst = gcs + (size_t)(key < n_lists ? key : 0) * p.cs_len;
+            const int n = key < n_lists ? (int)gcs_n[key] : 0;
+            const uint4 e03 = reinterpret_cast<const uint4 *>(lst)[0], e47 = reinterpret_cast<const uint4 *>(lst)[1];
+            if (n >= 2) {
                 const uint32_t e8[8] = {e03.x, e03.y, e03.z, e03.w, e47.x, e47.y, e47.z, e47.w};
-                for (int j = 0; j < nch && !elig; ++j) {
-                    const int raw = r->ch[j];
-                    if (raw & (1 << 14)) {
-                        const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
-                        bool sole = false, target = false;
+                if (n <= 8) {
+                    // greatest and second greatest residual capacity: entry a has a target iff some OTHER entry's free >= used_a
+                    int f1 = -1, f2 = -1, a1 = -1;
 #pragma unroll
-                        for (int t = 0; t < 8; ++t)
-                            if (t < n) {
-                                if (cs_ch(e8[t]) == ch) sole = sole || cs_used(e8[t]) == mine;
-                                else target = target || cs_free(e8[t]) >= mine;
-                            }
-                        for (int t = 8; t < n; t += 4) {  // four independent loads per round trip
-                            uint32_t en[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) en[q] = t + q < n ? lst[t + q] : 0u;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (t + q < n) {
-                                    if (cs_ch(en[q]) == ch) sole = sole || cs_used(en[q]) == mine;
-                                    else target = target || cs_free(en[q]) >= mine;
-                                }
+                    for (int t = 0; t < 8; ++t)
+                        if (t < n) {
+                            const int fr = cs_free(e8[t]);
+                            if (fr > f1) { f2 = f1; f1 = fr; a1 = t; } else if (fr > f2) { f2 = fr; }
                         }
-                        elig = sole && target;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (t < n) {
+                            const int best_other = t == a1 ? f2 : f1;
+                            if (best_other >= cs_used(e8[t])) {
+                                const uint32_t h = bm_hash(key, cs_ch(e8[t]), cs_used(e8[t]));
+                                atomicOr(bm + (h >> 5), 1u << (h & 31));
+                            }
+                        }
+                } else {
+                    int f1 = -1, f2 = -1, a1 = -1;
+                    for (int t = 0; t < n; ++t) {
+                        const int fr = cs_free(lst[t]);
+                        if (fr > f1) { f2 = f1; f1 = fr; a1 = t; } else if (fr > f2) { f2 = fr; }
+                    }
+                    for (int t = 0; t < n; ++t) {
+                        const uint32_t en = lst[t];
+                        if ((t == a1 ? f2 : f1) >= cs_used(en)) {
+                            const uint32_t h = bm_hash(key, cs_ch(en), cs_used(en));
+                            atomicOr(bm + (h >> 5), 1u << (h & 31));
+                        }
                     }
                 }
             }
         }
-        const u64 m = ballot(elig);
-        if (m) {
-            const int pos = n_el + popc64(m & ((1ull << lane) - 1ull));
-            if (elig && pos < p.cand_cap) { cand[pos].seq = seq; cand[pos].idx = (uint16_t)idx; }
-            n_el += popc64(m);
-        }
         wave_sync();
+        // (c) exact check of the services that passed, lane = service: as the reference's loop body up to the move
+        int n_maybe = 0;
+        auto resolve = [&]() {
+            for (int m0 = 0; m0 < n_maybe; m0 += 64) {
+                const bool on = m0 + lane < n_maybe;
+                const int idx = on ? (int)maybe[m0 + lane] : 0;
+                bool elig = false;
+                uint32_t seq = 0u;
+                int ekey = 0;
+                if (on) {
+                    const OrlgPhySvc *r = grec + idx;
+                    // (path and direction from the summary: the list's address does not wait for the record)
+                    const u64 sw = gsum[idx];
+                    const int gid = sum_gid(sw), nch = sum_nch(sw), flags = sum_flags(sw);
+                    seq = gseq[idx];
+                    const int key = svc_key(tb, N, K, gid, flags);
+                    ekey = key;
+                    const uint32_t *lst = gcs + (size_t)key * p.cs_len;
+                    const int n = gcs_n[key];
+                    const uint4 e03 = reinterpret_cast<const uint4 *>(lst)[0], e47 = reinterpret_cast<const uint4 *>(lst)[1];
+                    const uint32_t e8[8] = {e03.x, e03.y, e03.z, e03.w, e47.x, e47.y, e47.z, e47.w};
+                    for (int j = 0; j < nch && !elig; ++j) {
+                        const int raw = r->ch[j];
+                        if (raw & (1 << 14)) {
+                            const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
+                            bool sole = false, target = false;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+                                if (t < n) {
+                                    if (cs_ch(e8[t]) == ch) sole = sole || cs_used(e8[t]) == mine;
+                                    else target = target || cs_free(e8[t]) >= mine;
+                                }
+                            for (int t = 8; t < n; t += 4) {  // four independent loads per round trip
+                                uint32_t en[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) en[q] = t + q < n ? lst[t + q] : 0u;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (t + q < n) {
+                                        if (cs_ch(en[q]) == ch) sole = sole || cs_used(en[q]) == mine;
+                                        else target = target || cs_free(en[q]) >= mine;
+                                    }
+                            }
+                            elig = sole && target;
+                        }
+                    }
+                }
+                const u64 m = ballot(elig);
+                if (m) {
+                    const int pos = n_el + popc64(m & ((1ull << lane) - 1ull));
+                    if (elig && pos < p.cand_cap) { cand[pos].seq = seq; cand[pos].idx = (uint16_t)idx; cand[pos].gid = (uint16_t)ekey; }
+                    n_el += popc64(m);
+                }
+            }
+            n_maybe = 0;
+            wave_sync();
+        };
+        // (b) the services: KU summaries per lane requested at a time
+        for (int i0 = 0; i0 < n_running; i0 += 64 * KU) {
+            u64 sv[KU];
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int i = i0 + 64 * k + lane;
+                sv[k] = 0ull;
+                if (i < n_running) sv[k] = gsum[i];
+            }
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int i = i0 + 64 * k + lane;
+                bool hit = false;
+                if (i < n_running) {
+                    const u64 sw = sv[k];
+                    const int nch = sum_nch(sw);
+                    const int h0 = sum_ch(sw, 0), h1 = nch > 1 ? sum_ch(sw, 1) : 0;
+                    if (nch > 2) {
+                        hit = true;     // (channels beyond the summary: looked at exactly)
+                    } else if ((h0 | h1) & (1 << 14)) {
+                        const int key = svc_key(tb, N, K, sum_gid(sw), sum_flags(sw));
+                        if (h0 & (1 << 14)) { const uint32_t h = bm_hash(key, h0 & 0x1ff, (h0 >> 9) & 0x1f); hit = (bm[h >> 5] >> (h & 31)) & 1u; }
+                        if (!hit && (h1 & (1 << 14))) { const uint32_t h = bm_hash(key, h1 & 0x1ff, (h1 >> 9) & 0x1f); hit = (bm[h >> 5] >> (h & 31)) & 1u; }
+                    }
+                }
+                const u64 m = ballot(hit);
+                if (m) {
+                    if (hit) maybe[n_maybe + popc64(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+                    n_maybe += popc64(m);
+                }
+            }
+            wave_sync();
+            if (n_maybe > MAYBE_CAP - 64 * KU) resolve();
+        }
+        if (n_maybe > 0) resolve();
     }
     if (n_el > p.cand_cap) { overflow = true; n_el = p.cand_cap; }
     int gmoves = 0;
     SEC(8);   // defragmentation: grooming walk
     {
+        // The eligible services (seq, record index, list key) sit on lanes -- a cycle of the load-1400 workload has about a dozen,
+        // moves re-append theirs -- and a visit requests the service's record and its channel_state list together: one HBM round
+        // trip per visit.  More than a wavefront of them: the entries stay in the work list and every visit searches it.
+        const bool ereg = n_el + p.number_moves <= 64;
+        uint32_t eseq = 0u, ekx = 0u;    // lane e < n_el: entry e (seq; idx | key << 16)
+        if (ereg && lane < n_el) { eseq = cand[lane].seq; ekx = (uint32_t)cand[lane].idx | ((uint32_t)cand[lane].gid << 16); }
         long long cursor = -1;
         bool stop = p.number_moves == 0;  // the reference returns at its first check
         for (int visit = 0; visit < 2 * p.cand_cap && !stop; ++visit) {  // every visit moves the cursor up the list
-            uint32_t bs = 0u;
-            int bi = -1;
-            for (int c = lane; c < n_el; c += 64) {
-                const uint32_t sq = cand[c].seq;
-                if ((long long)sq > cursor && (bi < 0 || sq < bs)) { bs = sq; bi = (int)cand[c].idx; }
+            uint32_t seq0;
+            int idx, key;
+            if (ereg) {
+                const bool has = lane < n_el && (long long)eseq > cursor;
+                const double kmin = wave_min_key(eseq, has);
+                if (kmin < 0.0) break;
+                seq0 = (uint32_t)kmin;
+                const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane((int)ekx, ctz64(ballot(has && eseq == seq0)));
+                idx = (int)(kx & 0xffffu); key = (int)(kx >> 16);
+            } else {
+                uint32_t bs = 0u;
+                int bi = -1;
+                for (int c = lane; c < n_el; c += 64) {
+                    const uint32_t sq = cand[c].seq;
+                    if ((long long)sq > cursor && (bi < 0 || sq < bs)) { bs = sq; bi = (int)((uint32_t)cand[c].idx | ((uint32_t)cand[c].gid << 16)); }
+                }
+                const double kmin = wave_min_key(bs, bi >= 0);
+                if (kmin < 0.0) break;
+                seq0 = (uint32_t)kmin;
+                const uint32_t kx = (uint32_t)__builtin_amdgcn_readlane(bi, ctz64(ballot(bi >= 0 && bs == seq0)));
+                idx = (int)(kx & 0xffffu); key = (int)(kx >> 16);
             }
-            const double kmin = wave_min_key(bs, bi >= 0);
-            if (kmin < 0.0) break;
-            const uint32_t seq0 = (uint32_t)kmin;
-            const int idx = __builtin_amdgcn_readlane(bi, ctz64(ballot(bi >= 0 && bs == seq0)));
             const OrlgPhySvc *r = grec + idx;
-            const int gid = uni((int)r->gid), nch = uni((int)r->nch), flags = uni((int)r->flags);
-            if (lane < ORLG_PHY_MAX_CH) lch[lane] = lane < nch ? (int)r->ch[lane] : 0xffff;
+            // record and list, requested together
+            const uint32_t d3 = reinterpret_cast<const uint32_t *>(r)[3];   // gid | nch << 16 | flags << 24
+            const int chl = lane < ORLG_PHY_MAX_CH ? (int)r->ch[lane] : 0xffff;
+            CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
+            const int gid = uni((int)(d3 & 0xffffu)), nch = uni((int)((d3 >> 16) & 0xffu)), flags = uni((int)(d3 >> 24));
+            if (lane < ORLG_PHY_MAX_CH) lch[lane] = lane < nch ? chl : 0xffff;
             wave_sync();
-            const int key = svc_key(tb, N, K, gid, flags);
             const OrlgPathRec *rec = tb.recs + gid;
             bool moved = false;
             for (int j = 0; j < nch; ++j) {  // the list keeps its length: every move is remove + append
                 const int raw = lch[j];
                 if (raw & (1 << 14)) {
                     const int ch = raw & 0x1ff, mine = (raw >> 9) & 0x1f;
-                    CsList l = cs_load(gcs, gcs_n, key, lane, p.cs_len);
                     const int q = cs_find(l, ch, lane);
                     if (q >= 0 && cs_used(cs_get(l, q)) == mine) {
                         const u64 tm = ballot(lane < l.n && cs_ch(l.e) != ch && cs_free(l.e) >= mine);
@@ -889,7 +998,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                             cs_remove(l, ctz64(tm), lane);
                             cs_remove(l, cs_find(l, ch, lane), lane);
                             cs_append(l, cs_pack(cs_ch(tg), cs_used(tg) + mine, cs_free(tg) - mine, cs_cap(tg)), lane);
-                            cs_store(gcs, gcs_n, key, l, lane);
+                            cs_store(gcs, gcs_n, key, l, lane);   // (the list stays on lanes for the service's other channels)
                             // _move_virtual (:735-764): the old channel goes dark on the path, the list entry moves to the end
                             mc_before(occ, mc, ch, lane);
                             if (lane < rec->hops) occ[(int)rec->link[lane] * W + (ch >> 6)] |= 1ull << (ch & 63);
@@ -912,20 +1021,42 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const int ns = next_seq;
                 next_seq += 1;
                 if (lane < nch) grec[idx].ch[lane] = (uint16_t)lch[lane];
-                if (lane == 0) grec[idx].seq = (uint32_t)ns;
-                // the list iterator skips the service that followed this one (it slid into its place)
+                if (lane == 0) {
+                    grec[idx].seq = (uint32_t)ns;
+                    gsum[idx] = svc_summary(gid, flags, nch, (uint32_t)lch[0], nch > 1 ? (uint32_t)lch[1] : 0u);
+                    gseq[idx] = (uint32_t)ns;
+                }
+                // the list iterator skips the service that followed this one (it slid into its place): the smallest seq above
+                // seq0, from the dense seq array -- eight coalesced requests per lane in flight (the strided reads of the 48-byte
+                // records were a third of the defragmentation's HBM traffic)
                 uint32_t sm = 0u;
                 bool hs = false;
-                for (int i = lane; i < n_running; i += 64) {
-                    const uint32_t sq = grec[i].seq;
-                    if (sq > seq0 && (!hs || sq < sm)) { sm = sq; hs = true; }
+                if (!stop) {   // (the walk is over with the last move: nobody asks for the cursor)
+                    for (int i0 = 0; i0 < n_running; i0 += 512) {
+                        uint32_t v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = i0 + 64 * k + lane;
+                            v[k] = 0u;
+                            if (i < n_running && i != idx) v[k] = gseq[i];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int i = i0 + 64 * k + lane;
+                            const uint32_t sq = i == idx ? (uint32_t)ns : v[k];   // (this service's own new key: not read back)
+                            if (i < n_running && sq > seq0 && (!hs || sq < sm)) { sm = sq; hs = true; }
+                        }
+                    }
                 }
                 {
                     const double nk = wave_min_key(sm, hs);   // this service itself carries a later key: never "none"
                     cursor = nk < 0.0 ? (long long)seq0 : (long long)nk;
                 }
-                if (n_el < p.cand_cap) {
-                    if (lane == 0) { cand[n_el].seq = (uint32_t)ns; cand[n_el].idx = (uint16_t)idx; }
+                if (ereg) {
+                    if (lane == n_el) { eseq = (uint32_t)ns; ekx = (uint32_t)idx | ((uint32_t)key << 16); }
+                    n_el += 1;
+                } else if (n_el < p.cand_cap) {
+                    if (lane == 0) { cand[n_el].seq = (uint32_t)ns; cand[n_el].idx = (uint16_t)idx; cand[n_el].gid = (uint16_t)key; }
                     n_el += 1;
                 } else {
                     overflow = true;
@@ -941,142 +1072,209 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
     SEC(12);  // defragmentation: candidate scan
     if (gmoves <= p.number_moves) {
         int nc = 0;
+        const int base_cur = tb.pair_base[req_src * N + req_dst];
         if (gnv) nv_fence();   // the grooming pass may have returned channels
-        if (n_running > 0) svc_fetch(pf, grec, 0, n_running, CHUNK, lane);
-        for (int i0 = 0; i0 < n_running; i0 += CHUNK) {
-            const int cnt = n_running - i0 < CHUNK ? n_running - i0 : CHUNK;
-            svc_stash(pf, stage, cnt, lane);
+        // lane = service, from the record summaries (8 bytes: path, channel count, the first two channels) and the dense seq array;
+        // the record itself is read for the arrival time of a candidate and for the channels beyond the second -- one service in
+        // ten has them: those are set aside (LDS list) and scored afterwards, a wavefront of them at a time, instead of making
+        // every round of 64 services loop to the longest channel list among them.  The next 64 summaries are requested before the
+        // current ones are scored.
+        auto score = [&](int gid_, int ch_, const NvRec &nr_) -> double {
+            if (rss) return lane_rss_delta(occ, tb.sqrt_tab, tb.recs + gid_, ch_, E, W, 1, p.use_masks ? tb.masks + gid_ : nullptr);
+            if (gnv) {
+                // the service holds the channel on its whole path: c . D[ch] counts the free links towards off-path nodes and the
+                // free chords; gain of releasing = 2 * (that - chords) - wsum
+                int sdot = nv_dot(nr_.c, nv_get(gnv, ch_, p.C));
+                if (nr_.nchord) sdot -= nv_chords(occ, nr_, ch_, W);
+                return (double)(2 * sdot - nr_.wsum);
+            }
+            return (double)(-lane_cut_sum(occ, tb, gid_, ch_, W));
+        };
+        auto emit = [&](bool is_c, double diff, int idx, int jpos, int ch, int gid_, uint32_t seq_) {
+            const u64 m = ballot(is_c);
+            if (m) {
+                const int pos = nc + popc64(m & ((1ull << lane) - 1ull));
+                if (is_c && pos < p.cand_cap) {
+                    // (age, modulation level and table row are filled in when the candidates are ranked: cand_fill)
+                    OrlgPhyCand c;
+                    c.diff = diff; c.age = 0.0; c.seq = seq_; c.idx = (uint16_t)idx; c.chj = (uint16_t)(ch | (jpos << 9));
+                    c.gid = (uint16_t)gid_; c.pad0 = 0; c.pad1 = 0u;
+                    cand[pos] = c;
+                }
+                nc += popc64(m);
+            }
+        };
+        uint16_t *more = reinterpret_cast<uint16_t *>(r0w);   // services with more than two channels
+        constexpr int MORE_CAP = W * 64 * 8 / 2;
+        int n_more = 0;
+        auto score_more = [&]() {   // channels 2 .. of the services set aside: lane = service
+            for (int m0 = 0; m0 < n_more; m0 += 64) {
+                const bool act = m0 + lane < n_more;
+                const int idx = act ? (int)more[m0 + lane] : 0;
+                u64 sw = 0ull;
+                uint32_t my_seq = 0u, x5 = 0u, x6 = 0u, x7 = 0u;   // ch[2..7] of the record
+                if (act) {
+                    const uint32_t *rr = reinterpret_cast<const uint32_t *>(grec + idx);
+                    sw = gsum[idx]; my_seq = gseq[idx]; x5 = rr[5]; x6 = rr[6]; x7 = rr[7];
+                }
+                const int my_n = act ? sum_nch(sw) : 0, my_gid = sum_gid(sw);
+                NvRec nr = nv_unpack(make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u));
+                if (!rss && gnv && act) nr = nv_load(p.nvrec, my_gid);
+                const int maxn = wave_max_i32(my_n);
+                for (int jj = 2; jj < maxn; ++jj) {
+                    bool is_c = false;
+                    double diff = 0.0;
+                    int ch = 0;
+                    if (jj < my_n) {
+                        const int raw = jj < 8 ? (int)(((jj < 4 ? x5 : jj < 6 ? x6 : x7) >> (16 * (jj & 1))) & 0xffffu) : (int)grec[idx].ch[jj];
+                        if (!(raw & (1 << 14))) {  // only channels the service fills are reallocated
+                            ch = raw & 0x1ff;
+                            diff = score(my_gid, ch, nr);
+                            is_c = diff > 0.0;
+                        }
+                    }
+                    emit(is_c, diff, idx, jj, ch, my_gid, my_seq);
+                }
+            }
+            n_more = 0;
             wave_sync();
-            if (i0 + CHUNK < n_running) svc_fetch(pf, grec, i0 + CHUNK, n_running, CHUNK, lane);   // in flight during this chunk
+        };
+        u64 sw_n = 0ull;
+        uint32_t seq_n = 0u;
+        if (lane < n_running) { sw_n = gsum[lane]; seq_n = gseq[lane]; }
+        for (int i0 = 0; i0 < n_running; i0 += 64) {
             const int idx = i0 + lane;
-            const bool act = lane < cnt;
-            const OrlgPhySvc *r = stage + (act ? lane : 0);
-            const int my_n = act ? (int)r->nch : 0, my_gid = (int)r->gid;
-            const uint32_t my_seq = r->seq;
-            const double my_arrival = r->arrival;
-            int maxn = my_n;
-            maxn = wave_max_i32(maxn);
-            for (int j = 0; j < maxn; ++j) {
+            const bool act = idx < n_running;
+            const u64 sw = sw_n;
+            const uint32_t my_seq = seq_n;
+            if (idx + 64 < n_running) { sw_n = gsum[idx + 64]; seq_n = gseq[idx + 64]; }
+            const int my_n = act ? sum_nch(sw) : 0, my_gid = sum_gid(sw);
+            NvRec nr = nv_unpack(make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u));
+            if (!rss && gnv && act) nr = nv_load(p.nvrec, my_gid);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
                 bool is_c = false;
                 double diff = 0.0;
                 int ch = 0;
-                if (j < my_n) {
-                    const int raw = (int)r->ch[j];
+                if (jj < my_n) {
+                    const int raw = sum_ch(sw, jj);
                     if (!(raw & (1 << 14))) {  // only channels the service fills are reallocated
                         ch = raw & 0x1ff;
-                        if (rss) {
-                            diff = lane_rss_delta(occ, tb.sqrt_tab, tb.recs + my_gid, ch, E, W, 1, p.use_masks ? tb.masks + my_gid : nullptr);
-                        } else if (gnv) {
-                            // the service holds the channel on its whole path: c . D[ch] counts the free links towards
-                            // off-path nodes and the free chords; gain of releasing = 2 * (that - chords) - wsum
-                            const NvRec nr = nv_load(p.nvrec, my_gid);
-                            int s = nv_dot(nr.c, nv_get(gnv, ch, p.C));
-                            if (nr.nchord) s -= nv_chords(occ, nr, ch, W);
-                            diff = (double)(2 * s - nr.wsum);
-                        } else {
-                            diff = (double)(-lane_cut_sum(occ, tb, my_gid, ch, W));
-                        }
+                        diff = score(my_gid, ch, nr);
                         is_c = diff > 0.0;
                     }
                 }
-                const u64 m = ballot(is_c);
-                if (m) {
-                    const int pos = nc + popc64(m & ((1ull << lane) - 1ull));
-                    if (is_c && pos < p.cand_cap) {
-                        OrlgPhyCand c;
-                        c.diff = diff; c.age = current_time - my_arrival; c.seq = my_seq; c.idx = (uint16_t)idx; c.chj = (uint16_t)(ch | (j << 9));
-                        c.gid = (uint16_t)my_gid; c.pad0 = 0; c.pad1 = 0u;
-                        cand[pos] = c;
-                    }
-                    nc += popc64(m);
-                }
+                emit(is_c, diff, idx, jj, ch, my_gid, my_seq);
             }
-            wave_sync();   // the staging area is refilled by the next chunk
+            const u64 mm = ballot(my_n > 2);
+            if (mm) {
+                if (my_n > 2) more[n_more + popc64(mm & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+                n_more += popc64(mm);
+                wave_sync();
+                if (n_more > MORE_CAP - 64) score_more();
+            }
         }
+        if (n_more > 0) score_more();
         if (nc > p.cand_cap) { overflow = true; nc = p.cand_cap; }
         wave_sync();
         SEC(14);  // defragmentation: candidate rounds
         // The rounds are sequential (a move changes what the next candidate sees), but the ORDER of the candidates is fixed once
         // they are scanned -- sorted(key=(-diff, -age)), stable -- and a candidate's table data (its path's node weights, the
-        // modulation level of every channel on that path) do not depend on the moves either.  So: the candidates are fetched
-        // once into registers (lane l holds candidates l and l + 64; the load-1400 workload has ~100 per defragmentation), every
-        // candidate's rank in the sorted order is counted once (all pairs, the keys are distinct), round q takes the candidate
-        // of rank q, and the table reads of round q + 1 are in flight while round q is worked on.  The service record is only
-        // read when a move actually happens.  More than 128 candidates: the keys stay in HBM and a round searches them.
-        constexpr int RC = 2;                      // register-resident candidates per lane
-        const bool in_regs = nc <= 64 * RC;
-        double rd[RC], ra[RC];
-        u64 ro[RC];
-        uint32_t rx[RC], rg[RC];                   // idx | chj << 16, path record
-        int rank[RC];
-#pragma unroll
-        for (int s = 0; s < RC; ++s) {
-            rd[s] = -1.0; ra[s] = 0.0; ro[s] = ~0ull; rx[s] = 0u; rg[s] = 0u; rank[s] = 0x7fffffff;
-            const int c = lane + 64 * s;
-            if (in_regs && c < nc) {
-                rd[s] = cand[c].diff; ra[s] = cand[c].age;
-                ro[s] = ((u64)cand[c].seq << 4) | (u64)(cand[c].chj >> 9);
-                rx[s] = (uint32_t)cand[c].idx | ((uint32_t)cand[c].chj << 16);
-                rg[s] = (uint32_t)cand[c].gid;
-                rank[s] = 0;
+        // modulation level of every channel on that path) do not depend on the moves either.  So: every candidate's rank in the
+        // sorted order is counted once (all pairs, the keys are distinct; lane l holds candidates l, l + 64, ...: up to 256, the
+        // load-1400 workload has 90-190 per cycle), each lane writes its candidates to their sorted position behind the work list,
+        // and round q reads record q -- requested one round ahead, one dword per lane.  The service record is only read when a move
+        // actually happens.  More candidates than that: the keys stay where they are and every round searches them.
+        constexpr int RC = 4;                      // candidates per lane while the ranks are counted
+        const bool sorted = nc <= 64 * RC && 2 * nc <= p.cand_cap;
+        OrlgPhyCand *scand = cand + (p.cand_cap >> 1);
+        // the rest of a candidate's record, one candidate per lane: its age (the service's arrival time: one gather) and what its
+        // round will ask the QoT table -- the reference looks the candidate's path up among the k paths of the PENDING request
+        // (:388-394): right when both serve the same node pair, otherwise its loop runs out and leaves k - 1 -- the level of its
+        // channel on that column (:395) and the column itself
+        auto cand_fill = [&](uint4 &a, uint4 &b) {
+            const int idx_ = (int)(b.y & 0xffffu), ch_ = (int)((b.y >> 16) & 0x1ffu), gid_ = (int)(b.z & 0xffffu);
+            const double age = current_time - grec[idx_].arrival;
+            const int ridp = tb.pair_row[tb.path_pair[gid_]] * K + ((gid_ >= base_cur && gid_ < base_cur + K) ? gid_ - base_cur : K - 1);
+            const uint32_t level = (uint32_t)p.mod_t[(size_t)ridp * p.cpad + ch_];
+            a.z = (uint32_t)__double2loint(age); a.w = (uint32_t)__double2hiint(age);
+            b.z = (uint32_t)gid_ | (level << 16); b.w = (uint32_t)ridp;
+        };
+        if (!sorted) {
+            for (int c = lane; c < nc; c += 64) {
+                uint4 a = reinterpret_cast<const uint4 *>(cand + c)[0], b = reinterpret_cast<const uint4 *>(cand + c)[1];
+                cand_fill(a, b);
+                reinterpret_cast<uint4 *>(cand + c)[0] = a; reinterpret_cast<uint4 *>(cand + c)[1] = b;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_sync();
         }
-        if (in_regs) {
+        SEC(15);  // defragmentation: candidate ranks
+        if (sorted) {
+            uint4 v0[RC], v1[RC];                  // the lane's candidates: diff, age | seq, idx | chj << 16, gid, -
+            int rank[RC];
+#pragma unroll
+            for (int s = 0; s < RC; ++s) {
+                const int c = lane + 64 * s;
+                v0[s] = make_uint4(0u, 0u, 0u, 0u); v1[s] = v0[s];
+                rank[s] = 0;
+                if (c < nc) { v0[s] = reinterpret_cast<const uint4 *>(cand + c)[0]; v1[s] = reinterpret_cast<const uint4 *>(cand + c)[1]; }
+            }
+#pragma unroll
+            for (int s = 0; s < RC; ++s)
+                if (lane + 64 * s < nc) cand_fill(v0[s], v1[s]);
 #pragma unroll
             for (int t = 0; t < RC; ++t) {
                 const int cnt = nc - 64 * t < 64 ? nc - 64 * t : 64;
                 for (int l = 0; l < cnt; ++l) {   // candidate (l, t) against every lane's own
-                    const double jd = readlane_d(rd[t], l), ja = readlane_d(ra[t], l);
-                    const u64 jo = readlane64(ro[t], l);
+                    const double jd = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].y, l), __builtin_amdgcn_readlane((int)v0[t].x, l));
+                    const double ja = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].w, l), __builtin_amdgcn_readlane((int)v0[t].z, l));
+                    const uint32_t jx = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].x, l), jc = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].y, l);
+                    const u64 jo = ((u64)jx << 4) | (u64)(jc >> 25);   // order among equal (diff, age): running_services, then channel position
 #pragma unroll
-                    for (int s = 0; s < RC; ++s)
-                        rank[s] += (jd > rd[s] || (jd == rd[s] && (ja > ra[s] || (ja == ra[s] && jo < ro[s])))) ? 1 : 0;
+                    for (int s = 0; s < RC; ++s) {
+                        const double rd = __hiloint2double((int)v0[s].y, (int)v0[s].x), ra = __hiloint2double((int)v0[s].w, (int)v0[s].z);
+                        const u64 ro = ((u64)v1[s].x << 4) | (u64)(v1[s].y >> 25);
+                        rank[s] += (jd > rd || (jd == rd && (ja > ra || (ja == ra && jo < ro)))) ? 1 : 0;
+                    }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < RC; ++s) {
+                const int c = lane + 64 * s;
+                if (c < nc) { reinterpret_cast<uint4 *>(scand + rank[s])[0] = v0[s]; reinterpret_cast<uint4 *>(scand + rank[s])[1] = v1[s]; }
+            }
+            // other lanes of this wave read the sorted records back: the stores only have to be complete (same CU)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_sync();
         }
-        const int base_cur = tb.pair_base[req_src * N + req_dst];
-        // D of the lane's channels stays in registers over the rounds; a move patches the two entries it rewrote
-        uint4 dv[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) dv[w] = make_uint4(0u, 0u, 0u, 0u);
-        if (gnv && !rss) {
-            nv_fence();
-#pragma unroll
-            for (int w = 0; w < W; ++w) dv[w] = nv_get(gnv, 64 * w + lane, p.C);
+        // Round q's inputs -- the candidate's record (dword `lane` on lanes 0..7) and what the tables say about its path (the mask
+        // of the channels of its modulation level: lane w < W; its path's node weights: dword `lane`, lanes 0..7) -- are requested
+        // a round ahead (the record two), so that a round waits for no memory: it reads the path's free words and D from LDS,
+        // scores the free channels of that level, and touches the service record only when it moves.
+        SEC(14);  // defragmentation: candidate rounds
+        uint32_t rec_a = 0u, rec_b = 0u, tn_a = 0u;
+        u64 tm_a = 0ull;
+        auto issue_tables = [&](uint32_t rv, u64 &tm, uint32_t &tn) {
+            const uint32_t x6 = (uint32_t)__builtin_amdgcn_readlane((int)rv, 6), ridp = (uint32_t)__builtin_amdgcn_readlane((int)rv, 7);
+            if (lane < W) tm = p.lvl_mask[((size_t)ridp * 32 + ((x6 >> 16) & 31u)) * W + lane];
+            if (gnv && !rss && lane < 8) tn = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * (x6 & 0xffffu))[lane];
+        };
+        if (sorted && nc > 0) {
+            if (lane < 8) rec_a = reinterpret_cast<const uint32_t *>(scand)[lane];
+            if (nc > 1 && lane < 8) rec_b = reinterpret_cast<const uint32_t *>(scand + 1)[lane];
+            issue_tables(rec_a, tm_a, tn_a);
         }
-        // one candidate's round data: who it is, and what the tables say about its path
-        struct RoundData { double diff; int idx, ch, gid, level_l; int lev_w[W]; uint4 nr0, nr1; const uint8_t *mrow; bool valid; };
-        auto pick = [&](int q, RoundData &o) {   // the candidate of rank q (in_regs) and the loads of its table data
-            o.valid = false;
-            if (q >= nc) return;
-            const u64 m0 = ballot(rank[0] == q), m1 = ballot(rank[1] == q);
-            if ((m0 | m1) == 0ull) return;
-            const int wl = ctz64(m0 ? m0 : m1);
-            const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)(m0 ? rx[0] : rx[1]), wl);
-            o.gid = __builtin_amdgcn_readlane((int)(m0 ? rg[0] : rg[1]), wl);
-            o.diff = readlane_d(m0 ? rd[0] : rd[1], wl);
-            o.idx = (int)(x & 0xffffu); o.ch = (int)((x >> 16) & 0x1ffu);
-            o.valid = true;
-        };
-        auto fetch = [&](RoundData &o) {         // the reads of the QoT table and of the path's node weights, all in flight together
-            const int row = tb.pair_row[tb.path_pair[o.gid]];
-            // the reference looks the candidate's path up among the k paths of the PENDING request (:388-394): right
-            // when both serve the same node pair, otherwise its loop runs out and leaves k - 1
-            const int idp = (o.gid >= base_cur && o.gid < base_cur + K) ? o.gid - base_cur : K - 1;
-            o.mrow = p.mod_t + (size_t)(row * K + idp) * p.cpad;
-            o.level_l = (int)o.mrow[o.ch];
-#pragma unroll
-            for (int w = 0; w < W; ++w) o.lev_w[w] = (int)o.mrow[64 * w + lane];
-            o.nr0 = make_uint4(0u, 0u, 0u, 0u); o.nr1 = o.nr0;
-            if (gnv && !rss) { o.nr0 = p.nvrec[2 * o.gid]; o.nr1 = p.nvrec[2 * o.gid + 1]; }
-        };
-        RoundData cur;
-        cur.valid = false;
         for (int round = 0; round < nc; ++round) {  // every round retires one candidate
-            if (in_regs) {
-                pick(round, cur);
-                if (!cur.valid) break;
-                fetch(cur);
+            uint32_t cv, tnq = 0u;
+            u64 tmq = 0ull;
+            if (sorted) {
+                cv = rec_a; tmq = tm_a; tnq = tn_a;
+                rec_a = rec_b;
+                if (round + 2 < nc && lane < 8) rec_b = reinterpret_cast<const uint32_t *>(scand + round + 2)[lane];
+                if (round + 1 < nc) issue_tables(rec_a, tm_a, tn_a);
             } else {
                 // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
                 double bd = -1.0, ba = 0.0;
@@ -1096,69 +1294,71 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
                 const int wl = ctz64(ballot(bc >= 0 && bd == D && ba == A && (double)bo == O));
                 const int cb = __builtin_amdgcn_readlane(bc, wl);
-                cur.diff = D;
-                cur.idx = uni((int)cand[cb].idx); cur.ch = uni((int)(cand[cb].chj & 0x1ff)); cur.gid = uni((int)cand[cb].gid);
-                cur.valid = true;
+                cv = lane < 8 ? reinterpret_cast<const uint32_t *>(cand + cb)[lane] : 0u;
                 wave_sync();
                 if (lane == 0) cand[cb].diff = -1.0;
-                fetch(cur);
+                issue_tables(cv, tmq, tnq);
             }
-            const double diff = cur.diff;
-            const int idx = cur.idx, ch = cur.ch, gid = cur.gid;
+            const double diff = __hiloint2double(__builtin_amdgcn_readlane((int)cv, 1), __builtin_amdgcn_readlane((int)cv, 0));
+            const uint32_t x5 = (uint32_t)__builtin_amdgcn_readlane((int)cv, 5);
+            const int idx = (int)(x5 & 0xffffu), ch = (int)((x5 >> 16) & 0x1ffu);
+            const int gid = (int)((uint32_t)__builtin_amdgcn_readlane((int)cv, 6) & 0xffffu);
             const OrlgPhySvc *r = grec + idx;
             {
                 const OrlgPathRec *rec = tb.recs + gid;
-                const uint8_t *mrow = cur.mrow;
-                const int level = uni(cur.level_l);
+                // free on the path and of the candidate's modulation level: only those channels can take it over
                 u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
-                // only channels of the candidate's modulation level can take it over: words without one are not scored
-                {
-                    u64 mine = 0ull;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        const u64 same = ballot(cur.lev_w[w] == level);
-                        if (lane == w) mine = same;
-                    }
-                    acc &= mine;
-                }
+                acc &= lane < W ? tmq : 0ull;
                 int l0 = -1, c0 = -1;
                 double m0 = 0.0;
                 if (gnv && !rss) {
-                    // cut metric of the lane's channels from D (registers) and the path's node weights: an integer; the best
-                    // channel = greatest metric, then lowest channel number, as ONE key
-                    NvRec nr;
-                    {
-                        const uint4 bq = cur.nr1;
-                        nr.c = cur.nr0;
-                        nr.wsum = (int)(int16_t)(bq.x & 0xffffu); nr.cq = (int)(int16_t)(bq.x >> 16);
-                        nr.nchord = (int)(bq.y & 0xffu);
-                        nr.cl_lo = (bq.y >> 8) | (bq.z << 24); nr.cl_hi = (bq.z >> 8) & 0xffu;
-                        nr.cw_lo = (bq.z >> 16) | (bq.w << 16); nr.cw_hi = (bq.w >> 16) & 0xffu;
-                    }
-                    int key = -1;
+                    // cut metric of the lane's channels from D (LDS) and the path's node weights: an integer; the best channel =
+                    // greatest metric, then lowest channel number, as ONE key
+                    // Four rounds in five find a free channel of that level, one in fifteen moves: the vote "some channel's
+                    // metric beats -diff" comes first, the reduction to the best channel only when it passes.
+                    if (ballot(acc != 0ull) != 0ull) {
+                        uint4 qa, qb;
+                        qa.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 0); qa.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 1);
+                        qa.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 2); qa.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 3);
+                        qb.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 4); qb.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 5);
+                        qb.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 6); qb.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 7);
+                        const NvRec nr = nv_unpack(qa, qb);
+                        nv_fence();
+                        int key = -1;
+                        // -metric < diff with an integer metric and an integer-valued diff: metric + 1024 > 1024 - diff
+                        const int kthr = ((1024 - (int)diff) << 9) | 511;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        const u64 x = readlane64(acc, w);
-                        const int cc = 64 * w + lane;
-                        const bool fr = ((x >> lane) & 1ull) && cc < p.C;
-                        int s = nv_dot(nr.c, dv[w]) - nr.cq;
-                        if (nr.nchord) s -= nv_chords(occ, nr, cc, W);
-                        const int kk = ((nr.wsum - 2 * s + 1024) << 9) | (511 - cc);   // |metric| <= sum of the weights < 1024
-                        if (fr && kk > key) key = kk;
+                        for (int w = 0; w < W; ++w) {
+                            const u64 x = readlane64(acc, w);
+                            if (x == 0ull) continue;   // (wave-uniform: no free channel of that level in this word)
+                            const int cc = 64 * w + lane;
+                            const bool fr = ((x >> lane) & 1ull) && cc < p.C;
+                            int s = nv_dot(nr.c, nv_get(gnv, cc, p.C)) - nr.cq;
+                            if (nr.nchord) s -= nv_chords(occ, nr, cc, W);
+                            const int kk = ((nr.wsum - 2 * s + 1024) << 9) | (511 - cc);   // |metric| <= sum of the weights < 1024
+                            if (fr && kk > key) key = kk;
+                        }
+                        if (ballot(key > kthr) != 0ull) {
+                            key = wave_max_i32(key);
+                            l0 = 0; c0 = 511 - (key & 511); m0 = (double)((key >> 9) - 1024);
+                        }
                     }
-                    key = wave_max_i32(key);
-                    if (key >= 0) { l0 = 0; c0 = 511 - (key & 511); m0 = (double)((key >> 9) - 1024); }
                 } else {
                     int lv[W];
                     double mtr[W];
                     uint32_t cols[W];
+                    uint4 dv0[W];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dv0[w] = make_uint4(0u, 0u, 0u, 0u);
+                    const uint8_t *mrow = p.mod_t + (size_t)__builtin_amdgcn_readlane((int)cv, 7) * p.cpad;   // (levels: not looked at, flat)
                     phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
-                    phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv);
+                    phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv0);
                     phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
                 }
                 if (l0 >= 0 && -1.0 * m0 < diff) {
                     // _move (:662-697): the service's channel list is read now -- the moved entry goes to its end
-                    const int nch = uni((int)r->nch);
+                    const uint32_t d3 = (uint32_t)uni((int)reinterpret_cast<const uint32_t *>(r)[3]);   // gid | nch << 16 | flags << 24
+                    const int nch = (int)((d3 >> 16) & 0xffu), rflags = (int)(d3 >> 24);
                     const int mych = lane < nch ? (int)r->ch[lane] : 0xffff;
                     const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
                     if (jm) {
@@ -1174,21 +1374,22 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                         mc_after(occ, mc, c0, lane);
                         mc_after(occ, mc, ch, lane);
                         if (gnv) {
-                            const uint4 cv = p.nvrec[2 * gid];
-                            if (lane < 2) nv_update(gnv, cv, lane == 0 ? c0 : ch, lane != 0);
-#pragma unroll
-                            for (int w = 0; w < W; ++w) {   // the register copies of the two entries
-                                const int cc = 64 * w + lane;
-                                if (cc == c0) { dv[w].x -= cv.x; dv[w].y -= cv.y; dv[w].z -= cv.z; dv[w].w -= cv.w; }
-                                if (cc == ch) { dv[w].x += cv.x; dv[w].y += cv.y; dv[w].z += cv.z; dv[w].w += cv.w; }
-                            }
+                            const uint4 cv4 = p.nvrec[2 * gid];
+                            if (lane < 2) nv_update(gnv, cv4, lane == 0 ? c0 : ch, lane != 0);
                         }
                         const int nxtc = __shfl_down(mych, 1);
                         int nv2 = mych;
                         if (lane >= j && lane + 1 < nch) nv2 = nxtc;
                         if (lane == nch - 1) nv2 = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
                         if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv2;
-                        if (lane == 0) grec[idx].seq = (uint32_t)next_seq;
+                        {
+                            const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane(nv2, 0), h1 = (uint32_t)__builtin_amdgcn_readlane(nv2, 1);
+                            if (lane == 0) {
+                                grec[idx].seq = (uint32_t)next_seq;
+                                gsum[idx] = svc_summary(gid, rflags, nch, h0, nch > 1 ? h1 : 0u);
+                                gseq[idx] = (uint32_t)next_seq;
+                            }
+                        }
                         next_seq += 1;
                         cmoves += 1;
                         wave_sync();
@@ -1217,9 +1418,10 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
 template <int W>
 DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *rec, const uint8_t *mrow, int ch, int lane) {
     const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = 3.141592653589793;
-    const double bw = p.gn_bw, pw = p.gn_pw, att = p.gn_att, nf = p.gn_nf;
+    const double bw = p.gn_bw, pw = p.gn_pw, nf = p.gn_nf;
     const double fc = p.gn_cf[ch];
-    const double l_eff_a = 1 / (2 * att);
+    // the interferer terms of the lane's channels against channel ch: rows of the tables (coalesced over the lanes)
+    const double *rowA = p.gn_A + (size_t)ch * p.cpad, *rowR = p.gn_R + (size_t)ch * p.cpad;
     double A[W], B[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -1227,16 +1429,14 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
         const bool valid = c < p.C && c != ch;
         A[w] = 0.0; B[w] = 0.0;
         if (valid) {
-            const double sf = p.gn_cf[c];
             int se = (int)mrow[c];
             se = se < 1 ? 1 : (se > 6 ? 6 : se);
             const double pm = se <= 2 ? 1.0 : se == 3 ? 2.0 / 3 : se == 4 ? 17.0 / 25 : se == 5 ? 69.0 / 100 : 13.0 / 21;
-            A[w] = asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc + (bw / 2))) -
-                   asinh(pi * pi * fabs(beta_2) * l_eff_a * bw * (sf - fc - (bw / 2)));
-            B[w] = pm * (bw / fabs(sf - fc)) * 5 / 3;
+            A[w] = rowA[c];
+            B[w] = pm * rowR[c] * 5 / 3;
         }
     }
-    const double base = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4 * att));
+    const double base = p.gn_link[4 * p.E];
     const double r = pw / bw;
     double acc = 0.0;
     const int hops = rec->hops;
@@ -1250,19 +1450,16 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
             sb += lit ? B[w] : 0.0;
         }
         const double SA = wave_add_f64(sa), SB = wave_add_f64(sb);
-        const double len = p.gn_spanlen[link];
         const int ns = p.gn_nspans[link];
-        const double l_eff = (1 - exp(-2 * att * len * 1e3)) / (2 * att);
-        const double ratio = l_eff / (len * 1e3);
+        const double l_eff = p.gn_link[4 * link], ratio = p.gn_link[4 * link + 1], e1 = p.gn_link[4 * link + 2];
         const double sum_phi = base + (SA - (SB * ratio));
         const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sum_phi * bw;
-        const double power_ase = bw * h_plank * fc * (exp(2 * att * len * 1e3) - 1) * nf;
+        const double power_ase = bw * h_plank * fc * e1 * nf;
         const double g = 1 / (pw / (power_ase + power_nli_span));
         for (int s = 0; s < ns; ++s) acc += g;
     }
     return 10 * log10(1 / acc);
 }
-
 // DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
 // without it run the other one, whose registers are not shared with code they never execute
 // GN: ... and the one that also carries the GN-model admission check (orlg_gn_gate)
@@ -1291,6 +1488,14 @@ DEV uint32_t rec_store(OrlgPhySvc *dst, const double *arrival_lds, uint32_t seq,
     if (lane == 11) v = 0u;
     if (lane < 12) reinterpret_cast<uint32_t *>(dst)[lane] = v;
     return v;
+}
+// the side arrays of a new record (OrlgPhyParams::qsum / qseq): hw = the halfword of channel `lane` as rec_store takes it
+DEV void svc_side_store(u64 *gsum, uint32_t *gseq, int q, int gid, int flags, int nch, uint32_t hw, uint32_t seq, int lane) {
+    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hw, 0), h1 = (uint32_t)__builtin_amdgcn_readlane((int)hw, 1);
+    if (lane == 0) {
+        gsum[q] = svc_summary(gid, flags, nch, h0, nch > 1 ? h1 : 0u);
+        gseq[q] = seq;
+    }
 }
 // first service due at `time` among the near buffer's entries (earliest release, ties: lowest queue index)
 DEV void nb_first_due(const NearBuffer &nb, double time, int lane, int &victim, int &vpos, double &best_t) {
@@ -1373,6 +1578,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     }
     OrlgPhySvc *grec = p.qrec + (size_t)env * Q;
     double *gq = p.qtime + (size_t)env * Q;   // release times, compact: entries 0..n_running-1 are live
+    u64 *gsum = DF && p.qsum ? p.qsum + (size_t)env * Q : nullptr;        // side arrays of the records (defragmentation scans)
+    uint32_t *gseq = DF && p.qseq ? p.qseq + (size_t)env * Q : nullptr;
     nb.n = 0;
     nb.horizon = -__longlong_as_double((long long)ORLG_INF_BITS);  // the first look at the queue rebuilds the buffer
     uint32_t *gcs = p.cs + (size_t)env * N * N * K * p.cs_len;
@@ -1421,7 +1628,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     mc.total_runs = 0;
     mc.cterm = p.cterm ? p.cterm + (size_t)env * p.cpad : nullptr;
     mc.lterm = (double __attribute__((address_space(3))) *)scratch_d;
-    constexpr bool LT = !RSSP && !DF;   // the steps of this instantiation never touch scratch_d: the RSS terms stay there
+    // the steps of this instantiation never touch scratch_d: the RSS terms stay there (a defragmentation cycle uses the scratch:
+    // the terms go to the HBM array for its duration -- once in defrag_period steps instead of a round trip every step)
+    constexpr bool LT = !RSSP;
     mc.sqrt_tab = tb.sqrt_tab; mc.E = E; mc.W = W;
     if (mc.on) {
         double c0_unused, r0_unused;
@@ -1716,8 +1925,11 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     accepted = true;
                     if (n_running < Q) {
                         if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
-                        rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, 1 | (dirbit ? 2 : 0),
-                                  lane < nsel ? (uint32_t)(sel_ch[lane] | (sel_used[lane] << 9) | (1 << 14)) : 0xffffu, lane);
+                        {
+                            const uint32_t hw_v = lane < nsel ? (uint32_t)(sel_ch[lane] | (sel_used[lane] << 9) | (1 << 14)) : 0xffffu;
+                            rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, 1 | (dirbit ? 2 : 0), hw_v, lane);
+                            if (DF && gsum) svc_side_store(gsum, gseq, n_running, gid, 1 | (dirbit ? 2 : 0), nsel, hw_v, (uint32_t)next_seq, lane);
+                        }
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
@@ -1843,8 +2055,11 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     // _add_release: compact queue, append at n_running
                     if (n_running < Q) {
                         if (lane == 0) gq[n_running] = ws->req_arrival + ws->req_holding;
-                        rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, dirbit ? 2 : 0,
-                                  lane < nsel ? (uint32_t)(my_ch | (my_used << 9) | ((my_used != my_cap ? 1 : 0) << 14)) : 0xffffu, lane);
+                        {
+                            const uint32_t hw_p = lane < nsel ? (uint32_t)(my_ch | (my_used << 9) | ((my_used != my_cap ? 1 : 0) << 14)) : 0xffffu;
+                            rec_store(grec + n_running, &ws->req_arrival, (uint32_t)next_seq, gid, nsel, dirbit ? 2 : 0, hw_p, lane);
+                            if (DF && gsum) svc_side_store(gsum, gseq, n_running, gid, dirbit ? 2 : 0, nsel, hw_p, (uint32_t)next_seq, lane);
+                        }
                         {   // _add_release: the release joins the near-term buffer when it falls before the horizon
                             const double rel = readlane_d(ws->req_arrival + ws->req_holding, 0);
                             const int qidx = n_running;
@@ -2042,9 +2257,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 // every load of this release first (what was not requested ahead), every store last
                 const bool move_last = victim != n_running - 1;
                 uint32_t lastv = 0u;   // the queue's last record (lanes 0..11) and release time (12, 13): it takes the victim's place
-                if (move_last)
+                if (move_last) {
                     lastv = lane < 12 ? reinterpret_cast<const uint32_t *>(grec + (n_running - 1))[lane]
                                       : lane < 14 ? reinterpret_cast<const uint32_t *>(gq + (n_running - 1))[lane - 12] : 0u;
+                    if (DF && gsum) {   // its side-array entries travel with it (lanes 14, 15: summary; 16: seq)
+                        if (lane == 14 || lane == 15) lastv = reinterpret_cast<const uint32_t *>(gsum + (n_running - 1))[lane - 14];
+                        if (lane == 16) lastv = gseq[n_running - 1];
+                    }
+                }
                 uint32_t cvl = 0u;
                 if (gnv && lane < 4) cvl = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * sv_gid)[lane];
                 CsList l;
@@ -2099,6 +2319,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 if (move_last) {
                     if (lane < 12) reinterpret_cast<uint32_t *>(grec + victim)[lane] = lastv;
                     else if (lane < 14) reinterpret_cast<uint32_t *>(gq + victim)[lane - 12] = lastv;
+                    else if (DF && gsum && lane < 16) reinterpret_cast<uint32_t *>(gsum + victim)[lane - 14] = lastv;
+                    else if (DF && gsum && lane == 16) gseq[victim] = lastv;
                     for (int c0 = 0; c0 < nb.n; c0 += 64) {
                         const int c = c0 + lane;
                         if (c < nb.n && (int)nb.qi[c] == n_running) nb.qi[c] = (uint16_t)victim;
@@ -2120,8 +2342,23 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         SEC(11);  // defragmentation
             // periodic defragmentation (phy_rmsa_env.py:355-417): services_processed % defrag_period == 0
             wave_sync();
-            if (__builtin_expect(defrag_now, 1))   // (two thirds of the time of such a launch are spent in here: its loops get the registers)
-                phy_defragmentation<W>(p, tb, occ, ws, grec, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv, mc SEC_ARGS);
+            if (__builtin_expect(defrag_now, 1)) {   // (most of the time of such a launch is spent in here: its loops get the registers)
+                const bool park = LT && mc.on && mc.want_rss;
+                if (park) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        if (64 * w + lane < C) mc.cterm[64 * w + lane] = scratch_d[64 * w + lane];
+                    wave_sync();
+                }
+                phy_defragmentation<W>(p, tb, occ, ws, grec, gsum, gseq, gcs, gcs_n, gcand, sel_ch, scratch_d, n_running, next_seq, current_time, req_src, req_dst, lane, gnv, mc SEC_ARGS);
+                if (park) {   // (the cycle's own updates went to the HBM array; the terms past C are zero: ordered_sum_lds)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                    for (int w = 0; w < W; ++w) scratch_d[64 * w + lane] = 64 * w + lane < C ? mc.cterm[64 * w + lane] : 0.0;
+                    wave_sync();
+                }
+            }
         }
 
         if (p.mode == ORLG_MODE_STEP) {

@@ -98,6 +98,14 @@ def test_deeprmsa_observation_batch_32768(device_log_in_oracle):
         o.run("deeprmsa_sap_ff", 300, reset_on_done=True, fields=[])
         assert np.array_equal(obs[i], o.observation()), i
         o.close()
+    # float32 observations (orlg_deeprmsa_observation_f32): every element the float64 value rounded once, i.e. what an agent's
+    # obs.astype(np.float32) makes of the reference's Box(float64) vector
+    obs32 = env.observation(dtype=np.float32)
+    assert obs32.dtype == np.float32 and np.array_equal(obs32, obs.astype(np.float32))
+    buf = np.full((B, 54), 7.0, np.float32)
+    assert env.observation(out=buf) is buf and np.array_equal(buf, obs32)
+    with pytest.raises(TypeError):
+        env.observation(out=np.zeros((B, 54), np.float16))
     env.close()
 
 
@@ -129,3 +137,36 @@ def test_deeprmsa_synthetic_shapes(tmp_path, slots, j, device_log_in_oracle):
     for o in oracles:
         o.close()
     env.close()
+
+
+def test_deeprmsa_float32_observation_into_a_device_buffer():
+    """orlg_deeprmsa_observation_f32 writing straight into a caller's device buffer (a torch tensor: the agent loop of
+    bench.py) == the float64 observation rounded once.  In a child process: torch has to create its HIP context before the
+    library does, and this test process has long initialised the library."""
+    if STEP_KERNEL != "wave":
+        pytest.skip("the observation kernel is the same for both step kernels")
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        import numpy as np, torch
+        torch.zeros(1, device="cuda")
+        sys.path[:0] = [%r, %r]
+        from conftest import DEEPRMSA_NODE_PROBS, load_topology
+        from optical_rl_gym_amd import BatchedDeepRMSAEnv
+        B = 4099
+        env = BatchedDeepRMSAEnv(load_topology("nsfnet_chen_5-paths_6-modulations"), B, num_spectrum_resources=320, j=1,
+                                 mean_service_holding_time=7.5, mean_service_inter_arrival_time=1 / 12.0,
+                                 node_request_probabilities=DEEPRMSA_NODE_PROBS, episode_length=50, seed=3)
+        env.run("deeprmsa_sap_ff", 120, auto_reset=True)
+        t64 = torch.zeros((B, env.obs_dim), dtype=torch.float64, device="cuda")
+        t32 = torch.full((B, env.obs_dim), 7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        env.observation(out=t64); env.observation(out=t32)
+        env.synchronize()
+        a, b, h = t64.cpu().numpy(), t32.cpu().numpy(), env.observation()
+        assert np.array_equal(a, h) and np.array_equal(b, h.astype(np.float32)) and b.dtype == np.float32
+        print("f32 device buffer ok")
+    """) % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "f32 device buffer ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

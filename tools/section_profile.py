@@ -40,7 +40,7 @@ def main():
                                 defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None)
         names = ["idle/ticket", "state load", "policy: virtual layer", "policy: row metrics", "policy: channel selection", "provision",
                  "outputs", "next arrival + RNG", "defrag: grooming walk", "release: buffer / rebuild", "release apply (+ next scan)",
-                 "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", "dev"]
+                 "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", "defrag: candidate ranks"]
         env.run(args.phy, 3000, auto_reset=True)
         L = _lib.load()
         out = (C.c_ulonglong * 16)()
