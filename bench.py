@@ -342,28 +342,27 @@ def deeprmsa_record(clock, args):
     clock.barrier()
     el_pcie = time.perf_counter() - t0
     # (b) the same loop as an asynchronous vector environment runs it: float32 observations (what the agent's network takes),
-    # pinned host buffers, the batch in two halves on two streams -- the agent works on one half's observations while the other
-    # half steps, so the D2H of one half overlaps the H2D / step / observation build of the other
+    # pinned host buffers, the batch in four parts on four streams -- the agent works on one part's observations while the
+    # others step, so the D2H of one part overlaps the H2D / step / observation build of the others (tools/exp_pcie_loop.py:
+    # whole batch 122 M, halves 129 M, quarters 206 M env-steps/s; the host's issue cost, ~40 us per part, bounds it from there)
+    PARTS = 4
     halves = []
-    for h in range(2):
-        e2 = BatchedDeepRMSAEnv(topo, B // 2, num_spectrum_resources=320, j=1, mean_service_holding_time=7.5,
+    for h in range(PARTS):
+        e2 = BatchedDeepRMSAEnv(topo, B // PARTS, num_spectrum_resources=320, j=1, mean_service_holding_time=7.5,
                                 mean_service_inter_arrival_time=1 / 12.0, node_request_probabilities=DEEPRMSA_NODE_PROBS,
-                                episode_length=50, seed=10 + h * (B // 2))
+                                episode_length=50, seed=10 + h * (B // PARTS))
         st = torch.cuda.Stream(device=clock.dev)
         e2.set_stream(st.cuda_stream)
         halves.append(dict(env=e2, st=st, ev=torch.cuda.Event(),
-                           acts_h=torch.zeros(B // 2, dtype=torch.int32).pin_memory(),
-                           acts_d=torch.zeros(B // 2, dtype=torch.int32, device=clock.dev),
-                           obs_d=torch.empty((B // 2, env.obs_dim), dtype=torch.float32, device=clock.dev),
-                           obs_h=torch.empty((B // 2, env.obs_dim), dtype=torch.float32).pin_memory()))
+                           acts_h=torch.zeros(B // PARTS, dtype=torch.int32).pin_memory(),
+                           obs_h=torch.empty((B // PARTS, env.obs_dim), dtype=torch.float32).pin_memory()))
 
     def issue(hv):
-        with torch.cuda.stream(hv["st"]):
-            hv["acts_d"].copy_(hv["acts_h"], non_blocking=True)
-            hv["env"].run("deeprmsa_external", 1, actions=hv["acts_d"], auto_reset=True)
-            hv["env"].observation(out=hv["obs_d"])
-            hv["obs_h"].copy_(hv["obs_d"], non_blocking=True)
-            hv["ev"].record(hv["st"])
+        # pinned host buffers are used in place (include/orlg.h): the step kernel reads the actions, the observation kernel
+        # writes its rows over the bus -- no staging copies, three host calls per part and step
+        hv["env"].run("deeprmsa_external", 1, actions=hv["acts_h"], auto_reset=True)
+        hv["env"].observation(out=hv["obs_h"])
+        hv["ev"].record(hv["st"])
     for _ in range(300):
         for hv in halves:
             issue(hv)
@@ -392,8 +391,8 @@ def deeprmsa_record(clock, args):
             "step_kernel": step_kernel.split(" ")[0], "launch": step_kernel, "observation_kernel": "orlg_deeprmsa_obs_kernel<%d>" % W,
             "kernel_ms_step": float(np.mean(ks)), "kernel_ms_observation": float(np.mean(ko)), "obs_dim": obs_dim,
             "pcie_inclusive": {"value": B * n_pipe / el_pipe, "unit": "env steps/s", "ms_per_step": el_pipe * 1e3 / n_pipe,
-                               "what": "agent loop, two half-batches pipelined on two streams, pinned buffers: 4 B/env actions H2D, "
-                                       "%d B/env float32 observation D2H" % (4 * obs_dim),
+                               "what": "agent loop, four quarter-batches pipelined on four streams, pinned host buffers read / written in "
+                                       "place by the kernels: 4 B/env actions, %d B/env float32 observation" % (4 * obs_dim),
                                "serial_f64_pageable": {"value": B * n_pcie / el_pcie, "ms_per_step": el_pcie * 1e3 / n_pcie,
                                                        "what": "one blocking round trip per step, %d B/env float64 D2H" % (8 * obs_dim)}},
             "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),

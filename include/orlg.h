@@ -203,6 +203,10 @@ int orlg_deeprmsa_observation(orlg_env *env, double *out);
  * obs.astype(float32), which is what a stable-baselines agent does with the reference's Box(float64) observation: half the
  * bytes written and, for a host buffer, copied back */
 int orlg_deeprmsa_observation_f32(orlg_env *env, float *out);
+/* Both observation entries write `out` in place when it is device memory OR pinned host memory (hipHostMalloc, torch's
+ * pin_memory()): the kernel's stores then cross the bus themselves and the call returns without waiting, as for a device
+ * buffer (synchronise the stream or an event before reading).  Pageable host memory is staged and copied, and the call waits.
+ * The actions of orlg_step may likewise lie in pinned host memory. */
 int orlg_deeprmsa_obs_dim(orlg_env *env);
 
 /* SimpleMatrixObservation.observation() (rmsa_env.py:940-971) for every env: [B][2N + E*S] uint8 */

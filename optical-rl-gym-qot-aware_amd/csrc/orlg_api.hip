@@ -369,6 +369,19 @@ int orlg_is_device_ptr(const void *ptr) {
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// A pointer the kernels can use as it is: device / managed memory, or PINNED host memory (hipHostMalloc, torch's pin_memory),
+// which the device reaches over the bus -- returns the device-side alias, nullptr for pageable host memory
+void *orlg_device_alias(const void *ptr) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) return const_cast<void *>(ptr);
+    if (a.type == hipMemoryTypeHost && a.devicePointer) return a.devicePointer;
+    return nullptr;
+}
+
 // copy `bytes` from a device buffer to a caller pointer (host or device) and wait
 static int copy_out(orlg_env *e, void *dst, const void *src, size_t bytes) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, e->stream));
@@ -736,8 +749,8 @@ int orlg_step(orlg_env *e, int32_t policy, int32_t n_steps, const int32_t *actio
     p.mode = ORLG_MODE_STEP; p.n_steps = n_steps; p.policy = policy; p.auto_reset = auto_reset;
     if (ext) {
         size_t n = (size_t)p.B * (policy == ORLG_POLICY_EXTERNAL ? 2 : 1);
-        if (orlg_is_device_ptr(actions)) {
-            p.actions = actions;
+        if (const void *da = orlg_device_alias(actions)) {   // device memory, or pinned host memory read over the bus
+            p.actions = static_cast<const int32_t *>(da);
         } else {
             if (n > e->d_actions_cap) {
                 if (e->d_actions) HIP_TRY(hipFree(e->d_actions));
@@ -905,14 +918,17 @@ static int deeprmsa_observation(orlg_env *e, void *out, bool f32) {
     HIP_TRY(hipSetDevice(e->device));
     OrlgParams p = e->p;
     size_t bytes = (size_t)p.B * p.obs_dim * (f32 ? 4 : 8);
-    const bool dev = orlg_is_device_ptr(out);
+    // device memory -- or pinned host memory, which the kernel then writes over the bus, asynchronously like a device buffer
+    // (no staging copy, no wait: the caller synchronises the stream or an event) -- is written in place
+    void *alias = orlg_device_alias(out);
+    const bool dev = alias != nullptr;
     p.obs_f32 = f32 ? 1 : 0;
     if (!dev) {
         int rc = ensure_staging(e, bytes);
         if (rc) return rc;
         p.o_obs = reinterpret_cast<double *>(e->staging);
     } else {
-        p.o_obs = reinterpret_cast<double *>(out);
+        p.o_obs = reinterpret_cast<double *>(alias);
     }
     rmsa_kernel_t k = pick_obs(e->W);
     const int wpb = e->waves_per_block;

@@ -28,6 +28,7 @@ int orlg_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 // CPython _randommodule.c: random.Random(n) -> init_by_array(32-bit little-endian chunks of abs(n))
 void orlg_mt_seed(uint32_t *mt, uint64_t seed);
 int orlg_is_device_ptr(const void *ptr);
+void *orlg_device_alias(const void *ptr);
 
 // checkpoint / resume: the whole simulation state of a handle is a handful of flat device arrays
 struct OrlgStatePart { void *ptr; size_t bytes; };

@@ -951,6 +951,50 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
         const bool ereg = n_el + p.number_moves <= 64;
         uint32_t eseq = 0u, ekx = 0u;    // lane e < n_el: entry e (seq; idx | key << 16)
         if (ereg && lane < n_el) { eseq = cand[lane].seq; ekx = (uint32_t)cand[lane].idx | ((uint32_t)cand[lane].gid << 16); }
+        // A move makes the list iterator skip the service that FOLLOWED the moved one (it slides into its place): the walk needs
+        // the successor in list order of every entry it moves -- the smallest seq above the entry's own among all running
+        // services.  One pass over the dense seq array finds them all: the entries' seqs sorted in LDS, every service bisects
+        // for the entry it follows and lowers that entry's successor (LDS atomic minimum).  (Round 2 searched all records after
+        // every move: a third of the cycle's HBM traffic.)  Services that moved before an entry's turn lie below it in list
+        // order; the re-appended ones take consecutive seqs from ns_first on and follow every original service.
+        uint32_t esucc = 0xffffffffu;
+        const int ns_first = next_seq;
+        if (ereg && n_el > 0) {
+            int erank = 0;
+            for (int l2 = 0; l2 < n_el; ++l2) erank += ((uint32_t)__builtin_amdgcn_readlane((int)eseq, l2) < eseq) ? 1 : 0;
+            uint32_t *ss = reinterpret_cast<uint32_t *>(r0w), *sx = ss + 64;   // [64] sorted seqs, [64] their successors
+            if (lane < n_el) ss[erank] = eseq;
+            sx[lane] = 0xffffffffu;
+            wave_sync();
+            const int steps = 32 - __builtin_clz((unsigned)n_el);   // bisection over 0 .. n_el
+            for (int i0 = 0; i0 < n_running; i0 += 256) {
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + 64 * k + lane;
+                    v[k] = 0u;   // (below every entry: follows none)
+                    if (i < n_running) v[k] = gseq[i];
+                }
+                int lo[4], hi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lo[k] = 0; hi[k] = n_el; }
+                for (int it = 0; it < steps; ++it) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {   // entries with a seq below v[k]: the first `lo` of the sorted ones
+                        const int mid = (lo[k] + hi[k]) >> 1;
+                        const bool open = lo[k] < hi[k];
+                        const uint32_t sm_ = ss[open ? mid : 0];
+                        if (open) { if (sm_ < v[k]) lo[k] = mid + 1; else hi[k] = mid; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (lo[k] > 0) atomicMin(sx + (lo[k] - 1), v[k]);
+            }
+            wave_sync();
+            if (lane < n_el) esucc = sx[erank];
+            wave_sync();
+        }
         long long cursor = -1;
         bool stop = p.number_moves == 0;  // the reference returns at its first check
         for (int visit = 0; visit < 2 * p.cand_cap && !stop; ++visit) {  // every visit moves the cursor up the list
@@ -1031,7 +1075,14 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 // records were a third of the defragmentation's HBM traffic)
                 uint32_t sm = 0u;
                 bool hs = false;
-                if (!stop) {   // (the walk is over with the last move: nobody asks for the cursor)
+                if (ereg) {
+                    // the entry's successor from the table; none: it was the list's last service (then the first re-appended one
+                    // follows, or it follows itself), or a re-appended one (consecutive seqs)
+                    uint32_t sc = 0xffffffffu;
+                    if (seq0 < (uint32_t)ns_first) sc = (uint32_t)__builtin_amdgcn_readlane((int)esucc, ctz64(ballot(lane < n_el && eseq == seq0)));
+                    if (sc == 0xffffffffu) sc = seq0 < (uint32_t)ns_first ? (uint32_t)ns_first : seq0 + 1u;   // (<= ns: ns is this service's own new seq)
+                    sm = sc; hs = true;
+                } else if (!stop) {   // (the walk is over with the last move: nobody asks for the cursor)
                     for (int i0 = 0; i0 < n_running; i0 += 512) {
                         uint32_t v[8];
 #pragma unroll
@@ -1440,23 +1491,31 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
     const double r = pw / bw;
     double acc = 0.0;
     const int hops = rec->hops;
+    // the links' constants (effective length, its ratio to the span length, exp(2 att len) - 1, spans) for every hop at once:
+    // lane h = hop h, read back per hop by readlane -- one memory round trip per check instead of one per hop
+    double lk0 = 0.0, lk1 = 0.0, lk2 = 0.0;
+    int lkn = 0;
+    if (lane < hops) {
+        const int lnk = (int)rec->link[lane];
+        lk0 = p.gn_link[4 * lnk]; lk1 = p.gn_link[4 * lnk + 1]; lk2 = p.gn_link[4 * lnk + 2];
+        lkn = p.gn_nspans[lnk];
+    }
     for (int h = 0; h < hops; ++h) {
         const int link = (int)rec->link[h];
-        double sa = 0.0, sb = 0.0;
+        const double l_eff = readlane_d(lk0, h), ratio = readlane_d(lk1, h), e1 = readlane_d(lk2, h);
+        const int ns = __builtin_amdgcn_readlane(lkn, h);
+        // per interferer asinh(..) - asinh(..) - phi_mod (B / |df|) 5/3 l_eff / L, as calculate_osnr.py:33-45 sums them; one wave sum
+        double sphi = 0.0;
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const bool lit = !((occ[__mul24(link, W) + w] >> lane) & 1ull);   // (A, B are 0 on channels that do not exist)
-            sa += lit ? A[w] : 0.0;
-            sb += lit ? B[w] : 0.0;
+            sphi += lit ? (A[w] - (B[w] * ratio)) : 0.0;
         }
-        const double SA = wave_add_f64(sa), SB = wave_add_f64(sb);
-        const int ns = p.gn_nspans[link];
-        const double l_eff = p.gn_link[4 * link], ratio = p.gn_link[4 * link + 1], e1 = p.gn_link[4 * link + 2];
-        const double sum_phi = base + (SA - (SB * ratio));
+        const double sum_phi = base + wave_add_f64(sphi);
         const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sum_phi * bw;
         const double power_ase = bw * h_plank * fc * e1 * nf;
         const double g = 1 / (pw / (power_ase + power_nli_span));
-        for (int s = 0; s < ns; ++s) acc += g;
+        for (int sx = 0; sx < ns; ++sx) acc += g;
     }
     return 10 * log10(1 / acc);
 }

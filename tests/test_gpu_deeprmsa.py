@@ -166,6 +166,20 @@ def test_deeprmsa_float32_observation_into_a_device_buffer():
         env.synchronize()
         a, b, h = t64.cpu().numpy(), t32.cpu().numpy(), env.observation()
         assert np.array_equal(a, h) and np.array_equal(b, h.astype(np.float32)) and b.dtype == np.float32
+        # pinned host buffers are used in place (no staging copy, the call does not wait): observation rows written over the
+        # bus, actions read over it -- against the pageable-buffer path of a twin environment
+        twin = BatchedDeepRMSAEnv(load_topology("nsfnet_chen_5-paths_6-modulations"), B, num_spectrum_resources=320, j=1,
+                                  mean_service_holding_time=7.5, mean_service_inter_arrival_time=1 / 12.0,
+                                  node_request_probabilities=DEEPRMSA_NODE_PROBS, episode_length=50, seed=3)
+        twin.run("deeprmsa_sap_ff", 120, auto_reset=True)
+        p32 = torch.full((B, env.obs_dim), 7.0, dtype=torch.float32).pin_memory()
+        acts = torch.from_numpy(np.random.default_rng(1).integers(0, 6, B).astype(np.int32)).pin_memory()
+        for t in range(5):
+            env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
+            env.observation(out=p32)
+            env.synchronize()
+            twin.run("deeprmsa_external", 1, actions=acts.numpy().copy(), auto_reset=True)
+            assert np.array_equal(p32.numpy(), twin.observation(dtype=np.float32)), t
         print("f32 device buffer ok")
     """) % (root, os.path.join(root, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
