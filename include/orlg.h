@@ -213,6 +213,15 @@ int orlg_deeprmsa_obs_dim(orlg_env *env);
 int orlg_simple_matrix_observation(orlg_env *env, uint8_t *out);
 int orlg_simple_matrix_obs_dim(orlg_env *env);
 
+/* Every environment gets a fresh random.Random -- seeds[i] if given, else base_seed + i -- and nothing else changes: the
+ * pending request stays, the next arrival is the new generator's first draw (arrivals pre-generated from the old generator
+ * are dropped).  This is NOT OpticalNetworkEnv.seed (optical_network_env.py:266-271) called after construction: the
+ * reference's bit-rate draw stays bound to the generator object of construction time (functools.partial(self.rng.choices,
+ * ...), rmsa_env.py:109-111, phy_rmsa_env.py:130-132), so there a request then takes four draws from the new generator and
+ * the bit rate from the old one (tests/golden/seed_rmsa_nsfnet_s10.npz pins it; the oracle restates it).  Here all five
+ * come from the new generator; the gym views refuse seed() for that reason. */
+int orlg_reseed(orlg_env *env, const uint64_t *seeds, uint64_t base_seed);
+
 /* checkpoint / resume (the reference has none for environment state): the complete simulation state
  * of the handle -- occupancy, release queue, RNG, pending requests, counters, statistics -- as one flat blob of
  * orlg_state_size() bytes (host or device buffer).  A blob only fits a handle created with the same arguments.
@@ -355,6 +364,8 @@ int orlg_phy_get_episode_stats(orlg_phy_env *env, orlg_phy_episode_stats *out /*
 /* topology.graph["available_channels"] as a bitmap [B][E][W] uint64 */
 int orlg_phy_get_occupancy(orlg_phy_env *env, uint64_t *out);
 int orlg_phy_reduce_counters(orlg_phy_env *env, int64_t *out /* [16] as orlg_reduce_counters */);
+/* as orlg_reseed */
+int orlg_phy_reseed(orlg_phy_env *env, const uint64_t *seeds, uint64_t base_seed);
 /* checkpoint / resume, as orlg_save_state */
 int64_t orlg_phy_state_size(orlg_phy_env *env);
 int orlg_phy_save_state(orlg_phy_env *env, void *buffer);

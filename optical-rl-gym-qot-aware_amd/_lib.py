@@ -111,6 +111,7 @@ def load(build_if_missing=True):
     L.orlg_last_kernel.argtypes = [vp, C.c_char_p, i32]
     L.orlg_phy_last_kernel.argtypes = [vp, C.c_char_p, i32]
     L.orlg_reset.argtypes = [vp, i32]
+    L.orlg_reseed.argtypes = [vp, vp, C.c_uint64]
     L.orlg_step.argtypes = [vp, i32, i32, vp, i32, C.POINTER(StepIO)]
     L.orlg_get_requests.argtypes = [vp, vp]
     L.orlg_get_counters.argtypes = [vp, vp]
@@ -135,6 +136,7 @@ def load(build_if_missing=True):
     L.orlg_phy_set_stream.argtypes = [vp, vp]
     L.orlg_phy_synchronize.argtypes = [vp]
     L.orlg_phy_reset.argtypes = [vp, i32]
+    L.orlg_phy_reseed.argtypes = [vp, vp, C.c_uint64]
     L.orlg_phy_step.argtypes = [vp, i32, i32, vp, vp, i32, C.POINTER(PhyStepIO)]
     L.orlg_phy_words_per_link.argtypes = [vp]
     L.orlg_phy_node_vectors.argtypes = [vp]
@@ -157,12 +159,12 @@ def load(build_if_missing=True):
 
 EXPORTED_SYMBOLS = [
     "orlg_abi_version", "orlg_last_error", "orlg_device_count", "orlg_create", "orlg_destroy", "orlg_set_stream",
-    "orlg_synchronize", "orlg_launch_info", "orlg_last_kernel", "orlg_phy_last_kernel", "orlg_reset", "orlg_step", "orlg_get_requests", "orlg_get_counters",
+    "orlg_synchronize", "orlg_launch_info", "orlg_last_kernel", "orlg_phy_last_kernel", "orlg_reset", "orlg_reseed", "orlg_step", "orlg_get_requests", "orlg_get_counters",
     "orlg_get_current_time", "orlg_get_occupancy", "orlg_words_per_link", "orlg_get_link_stats",
     "orlg_get_graph_stats", "orlg_get_bit_rate_hist", "orlg_get_num_running", "orlg_get_episodes_done",
     "orlg_query_path_masks", "orlg_query_path_mask", "orlg_deeprmsa_observation", "orlg_deeprmsa_observation_f32", "orlg_deeprmsa_obs_dim", "orlg_reduce_counters",
     "orlg_simple_matrix_observation", "orlg_simple_matrix_obs_dim", "orlg_host_log",
-    "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset",
+    "orlg_phy_create", "orlg_phy_destroy", "orlg_phy_set_stream", "orlg_phy_synchronize", "orlg_phy_reset", "orlg_phy_reseed",
     "orlg_phy_step", "orlg_phy_words_per_link", "orlg_phy_node_vectors", "orlg_phy_get_requests", "orlg_phy_get_counters",
     "orlg_phy_get_current_time", "orlg_phy_get_num_running", "orlg_phy_get_episode_stats",
     "orlg_phy_get_occupancy", "orlg_phy_reduce_counters", "orlg_phy_get_channel_state",

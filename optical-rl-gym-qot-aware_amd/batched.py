@@ -163,6 +163,21 @@ class BatchedRMSAEnv:
     def reset(self, only_episode_counters: bool = True):
         _lib.check(self.L.orlg_reset(self.h, 1 if only_episode_counters else 0))
 
+    def reseed(self, seed=None, seeds=None):
+        """A fresh ``random.Random`` for every environment -- ``seeds[i]`` if given, else ``seed + i`` (the constructor's
+        convention) -- and nothing else changes: the pending requests stay, the next arrivals are the new generators' first
+        draws.  NOT the reference's ``seed()``: there the bit-rate draw stays bound to the generator object of construction time
+        (``functools.partial(self.rng.choices, ...)``, ``rmsa_env.py:109-111``), so after ``env.seed(s)`` the reference takes
+        inter-arrival time, holding time, source and destination from ``Random(s)`` and the bit rate from the OLD generator
+        (pinned by ``tests/golden/seed_rmsa_nsfnet_s10.npz``); here all five draws come from the new one."""
+        if seeds is not None:
+            sa = np.ascontiguousarray(seeds, np.uint64)
+            if sa.shape != (self.batch_size,):
+                raise ValueError(f"seeds: shape {sa.shape}, expected ({self.batch_size},)")
+            _lib.check(self.L.orlg_reseed(self.h, _ptr(sa), 0))
+        else:
+            _lib.check(self.L.orlg_reseed(self.h, None, int(41 if seed is None else seed)))
+
     def run(self, policy: str, n_steps: int = 1, *, actions=None, auto_reset: bool = False,
             outputs: Sequence[str] = (), out: Optional[Dict[str, object]] = None):
         """``n_steps`` x (policy -> step) on the device.  ``outputs`` names per-step arrays to return

@@ -734,6 +734,26 @@ int orlg_reset(orlg_env *e, int32_t only_episode_counters) {
     return launch_rmsa(e, p);
 }
 
+__global__ void orlg_reseed_kernel(OrlgEnvScalars *scal, int B) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        scal[i].mt_idx = ORLG_MT_N;               // a freshly seeded generator: the first draw regenerates the state
+        scal[i].ring_pos = 0; scal[i].ring_cnt = 0;   // arrivals pre-generated from the old generator are dropped
+    }
+}
+int orlg_reseed(orlg_env *e, const uint64_t *seeds, uint64_t base_seed) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int B = e->p.B;
+    std::vector<uint32_t> mt((size_t)B * ORLG_MT_N);
+    for (int i = 0; i < B; i++) orlg_mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+    HIP_TRY(hipMemcpyAsync(e->p.mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(orlg_reseed_kernel, dim3(64), dim3(256), 0, e->stream, e->p.scal, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORLG_OK;
+}
+
 // io slot ids
 enum { IO_PATH, IO_SLOT, IO_ACC, IO_DONE, IO_REWARD, IO_REQ, IO_ARR, IO_HOLD, IO_COMP, IO_CDIFF };
 

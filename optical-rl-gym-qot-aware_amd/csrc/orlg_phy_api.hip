@@ -139,6 +139,12 @@ __global__ void orlg_gn_tables_kernel(const OrlgPhyParams p, double *A, double *
     if (blockIdx.x == 0 && threadIdx.x == 0) L[4 * p.E] = asinh(pi * pi * fabs(beta_2) * (bw * bw) / (4 * att));
 }
 
+__global__ void orlg_phy_reseed_kernel(OrlgPhyScalars *scal, int B) {   // as orlg_reseed_kernel
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        scal[i].mt_idx = ORLG_MT_N;
+        scal[i].ring_pos = 0; scal[i].ring_cnt = 0;
+    }
+}
 // the sticky error word recomputed from the scalars (orlg_phy_load_state; mapped host memory: a plain store)
 __global__ void orlg_phy_overflow_store_kernel(const OrlgPhyScalars *scal, int B, int *err_flag) {
     int any = 0;
@@ -597,6 +603,20 @@ int orlg_phy_set_stream(orlg_phy_env *e, void *hip_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
     }
+    return ORLG_OK;
+}
+
+int orlg_phy_reseed(orlg_phy_env *e, const uint64_t *seeds, uint64_t base_seed) {
+    if (!e) return fail(ORLG_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int B = e->p.B;
+    std::vector<uint32_t> mt((size_t)B * ORLG_MT_N);
+    for (int i = 0; i < B; i++) orlg_mt_seed(&mt[(size_t)i * ORLG_MT_N], seeds ? seeds[i] : base_seed + (uint64_t)i);
+    HIP_TRY(hipMemcpyAsync(e->p.mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(orlg_phy_reseed_kernel, dim3(64), dim3(256), 0, e->stream, e->p.scal, B);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return ORLG_OK;
 }
 

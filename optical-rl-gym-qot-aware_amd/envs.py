@@ -216,7 +216,12 @@ class RMSAEnv:
         return 1 if self.current_service.accepted else 0
 
     def seed(self, seed=None):
-        raise NotImplementedError("the RNG lives on the device: pass seed= to the constructor")
+        """``optical_network_env.py:266-271``; see ``BatchedRMSAEnv.reseed`` for why this is refused."""
+        raise NotImplementedError(
+            "seed() after construction is not reproduced: the reference keeps drawing the BIT RATE from the generator object of "
+            "construction time (functools.partial(self.rng.choices, ...)) while the other four draws of a request come from "
+            "Random(seed) -- two generators per environment.  Pass seed= to the constructor, or call reseed() on the batched "
+            "environment for a fresh generator for all draws (not the reference's stream).")
 
     def render(self, mode="human"):
         return

@@ -181,6 +181,16 @@ class BatchedPhyRMSAEnv:
         _lib.check(self.L.orlg_phy_last_kernel(self.h, buf, 128))
         return buf.value.decode()
 
+    def reseed(self, seed=None, seeds=None):
+        """A fresh generator for every environment: see ``BatchedRMSAEnv.reseed`` (NOT the reference's ``seed()``)."""
+        if seeds is not None:
+            sa = np.ascontiguousarray(seeds, np.uint64)
+            if sa.shape != (self.batch_size,):
+                raise ValueError(f"seeds: shape {sa.shape}, expected ({self.batch_size},)")
+            _lib.check(self.L.orlg_phy_reseed(self.h, _ptr(sa), 0))
+        else:
+            _lib.check(self.L.orlg_phy_reseed(self.h, None, int(41 if seed is None else seed)))
+
     def run(self, policy: str, n_steps: int = 1, *, act_path=None, act_channels=None, auto_reset: bool = False,
             outputs: Sequence[str] = (), out=None):
         """``n_steps`` x (policy -> PhyRMSAEnv.step).  ``policy='external'``: ``act_path`` [B] int32 (-2 = blocked,

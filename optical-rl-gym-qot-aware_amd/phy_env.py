@@ -174,6 +174,14 @@ class PhyRMSAEnv:
     def render(self, mode="human"):
         return
 
+    def seed(self, seed=None):
+        """``optical_network_env.py:266-271``; see ``BatchedRMSAEnv.reseed`` for why this is refused."""
+        raise NotImplementedError(
+            "seed() after construction is not reproduced: the reference keeps drawing the BIT RATE from the generator object of "
+            "construction time (functools.partial(self.rng.choices, ...)) while the other four draws of a request come from "
+            "Random(seed) -- two generators per environment.  Pass seed= to the constructor, or call reseed() on the batched "
+            "environment for a fresh generator for all draws (not the reference's stream).")
+
     def reset(self, only_episode_counters: bool = True):
         self._batched.reset(only_episode_counters)
         self._sync()

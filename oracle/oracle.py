@@ -89,6 +89,8 @@ def lib(asan=False):
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.POINTER(Topology), C.POINTER(Config), C.c_uint64]
         L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_reset.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_request.argtypes = [C.c_void_p, C.POINTER(Request)]
         L.orc_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(StepResult)]
@@ -165,6 +167,15 @@ class OracleEnv:
             self.close()
         except Exception:
             pass
+
+    def seed(self, seed):
+        """OpticalNetworkEnv.seed: a fresh random.Random(seed) (optical_network_env.py:266-271) -- the bit-rate draw stays bound to
+        the old generator, as in the reference (orc_seed)."""
+        self.L.orc_seed(self.h, C.c_uint64(41 if seed is None else seed))
+
+    def reseed(self, seed):
+        """Not the reference: a fresh generator for all five draws (the device's orlg_reseed)."""
+        self.L.orc_reseed(self.h, C.c_uint64(seed))
 
     def reset(self, only_episode_counters=True):
         self.L.orc_reset(self.h, 1 if only_episode_counters else 0)
@@ -334,6 +345,8 @@ def _phy_lib(asan=False):
         L.orc_phy_create.restype = C.c_void_p
         L.orc_phy_create.argtypes = [C.POINTER(Topology), C.POINTER(PhyConfig), C.c_uint64]
         L.orc_phy_destroy.argtypes = [C.c_void_p]
+        L.orc_phy_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_phy_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_phy_reset.argtypes = [C.c_void_p, C.c_int]
         L.orc_phy_get_request.argtypes = [C.c_void_p, C.POINTER(Request)]
         L.orc_phy_policy.argtypes = [C.c_void_p, C.c_int, C.POINTER(PhyAction)]
@@ -414,6 +427,12 @@ class PhyOracleEnv:
             self.close()
         except Exception:
             pass
+
+    def seed(self, seed):
+        self.L.orc_phy_seed(self.h, C.c_uint64(41 if seed is None else seed))
+
+    def reseed(self, seed):
+        self.L.orc_phy_reseed(self.h, C.c_uint64(seed))
 
     def reset(self, only_episode_counters=True):
         self.L.orc_phy_reset(self.h, 1 if only_episode_counters else 0)

@@ -41,6 +41,8 @@ struct orc_env {
     orc_config cfg;
     int N, E, S, K;
     py_rng rng;
+    py_rng rng_br;   /* after seed(): the generator the bit-rate partial stays bound to (see orc_seed) */
+    int split;
     uint8_t *available;  /* topology.graph["available_slots"], E*S, 1 = free */
     /* per link (rmsa_env.py:562-641, optical_network_env.py:260-264) */
     double *l_util, *l_extfrag, *l_compact, *l_last_update;
@@ -297,7 +299,7 @@ static void next_service(orc_env *e) {
     double ht = py_expovariate(&e->rng, e->cfg.holding_lambda);
     int src = py_choice_cum(&e->rng, e->cfg.src_cum, e->N);
     int dst = py_choice_cum(&e->rng, e->cfg.dst_cum + (size_t)src * e->N, e->N);
-    int bri = py_choice_cum(&e->rng, e->cfg.bit_rate_cum, e->cfg.num_bit_rates);
+    int bri = py_choice_cum(e->split ? &e->rng_br : &e->rng, e->cfg.bit_rate_cum, e->cfg.num_bit_rates);
 
     service *s = (service *)calloc(1, sizeof(service));
     s->service_id = (int32_t)e->c.episode_services_processed;
@@ -365,6 +367,18 @@ void orc_reset(orc_env *e, int only_episode_counters) {
     }
     full_reset(e);
 }
+
+/* OpticalNetworkEnv.seed (optical_network_env.py:266-271): self.rng = random.Random(seed), nothing else changes.  A quirk
+ * comes with it: the constructors bind the bit-rate draw to the generator OBJECT of that moment -- functools.partial(
+ * self.rng.choices, ...) (rmsa_env.py:109-111, phy_rmsa_env.py:130-132) -- so after a later seed() inter-arrival time, holding
+ * time, source and destination come from the new generator and the bit rate still from the old one, which carries on where
+ * it was. */
+void orc_seed(orc_env *e, uint64_t seed) {
+    if (!e->split) { e->rng_br = e->rng; e->split = 1; }
+    py_seed(&e->rng, seed);
+}
+/* NOT the reference: a fresh generator for all five draws of a request (what the device's orlg_reseed does) */
+void orc_reseed(orc_env *e, uint64_t seed) { py_seed(&e->rng, seed); e->split = 0; }
 
 orc_env *orc_create(const orc_topology *topo, const orc_config *cfg, uint64_t seed) {
     orc_env *e = (orc_env *)calloc(1, sizeof(orc_env));

@@ -85,6 +85,8 @@ typedef struct orc_counters {
 typedef struct orc_env orc_env;
 
 orc_env *orc_create(const orc_topology *topo, const orc_config *cfg, uint64_t seed);
+void orc_seed(orc_env *e, uint64_t seed);
+void orc_reseed(orc_env *e, uint64_t seed);
 void orc_destroy(orc_env *e);
 void orc_reset(orc_env *e, int only_episode_counters);
 void orc_get_request(const orc_env *e, orc_request *out);

@@ -83,6 +83,8 @@ typedef struct orc_phy_trace {
 typedef struct orc_phy_env orc_phy_env;
 
 orc_phy_env *orc_phy_create(const orc_topology *topo, const orc_phy_config *cfg, uint64_t seed);
+void orc_phy_seed(orc_phy_env *e, uint64_t seed);
+void orc_phy_reseed(orc_phy_env *e, uint64_t seed);
 void orc_phy_destroy(orc_phy_env *e);
 void orc_phy_reset(orc_phy_env *e, int only_episode_counters);
 void orc_phy_get_request(const orc_phy_env *e, orc_request *out);

@@ -304,6 +304,33 @@ def gen_rmsa():
               "compactness", out["network_compactness"][-1])
 
 
+# --------------------------------------------------------------------------- seed() in the middle of a run
+def gen_seed():
+    """OpticalNetworkEnv.seed (optical_network_env.py:266-271) called between two steps: a fresh random.Random(seed), nothing
+    else changes -- the pending request stays, the next arrival is the new generator's first draw.  RMSAEnv and PhyRMSAEnv."""
+    from optical_rl_gym.envs import rmsa_env as R
+    topo = load_pickled_topology(TOPOLOGIES["nsfnet_chen_5-paths_6-modulations"])
+    kw = dict(RMSA_BASE, seed=10)
+    env = R.RMSAEnv(topology=topo, **kw)
+    rows = []
+    for t in range(120):
+        if t == 40:
+            env.seed(77)
+        if t == 80:
+            env.seed()          # the default: 41
+        s = env.current_service
+        a = R.shortest_available_path_first_fit(env)
+        env.step(a)
+        rows.append((s.source_id, s.destination_id, s.bit_rate, s.arrival_time, s.holding_time, a[0], a[1], int(s.accepted)))
+    r = np.array(rows, dtype=np.float64)
+    meta = dict(topology="nsfnet_chen_5-paths_6-modulations", env_kwargs=_jsonable(kw), policy="sap_ff", steps=120,
+                reseed={"40": 77, "80": None})
+    np.savez_compressed(os.path.join(HERE, "seed_rmsa_nsfnet_s10.npz"), src=r[:, 0].astype(np.int32), dst=r[:, 1].astype(np.int32),
+                        bit_rate=r[:, 2].astype(np.int32), arrival=r[:, 3], holding=r[:, 4], act_path=r[:, 5].astype(np.int32),
+                        act_slot=r[:, 6].astype(np.int32), accepted=r[:, 7].astype(np.uint8), meta=np.array(json.dumps(meta)))
+    print("seed_rmsa_nsfnet_s10: accepted", int(r[:, 7].sum()), "of 120; arrival[41] =", r[41, 3])
+
+
 # --------------------------------------------------------------------------- RMSA wrappers
 def gen_wrappers():
     """SimpleMatrixObservation (rmsa_env.py:940-971) and PathOnlyFirstFitAction (:974-1008) on RMSA-v0."""
@@ -639,7 +666,7 @@ def main():
     install_gym_stub()
     import optical_rl_gym  # noqa: F401  (registers env ids)
 
-    todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "deeprmsa", "phy", "osnr"]
+    todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "seed", "deeprmsa", "phy", "osnr"]
     for what in todo:
         fn = globals().get("gen_" + what)
         if what == "phy" and args.case:

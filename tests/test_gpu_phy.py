@@ -442,3 +442,28 @@ def test_gn_gate_batch_4096(device_log_in_oracle):
     assert red["num_envs"] == batch and red["services_processed"] == batch * (n + 1)
     assert env.episode_stats()["queue_overflow"].max() == 0
     env.close()
+
+
+def test_phy_reseed_between_launches_vs_oracle(device_log_in_oracle):
+    """orlg_phy_reseed (a fresh generator for all five draws of a request: see orlg_reseed in include/orlg.h) between launches,
+    with the defragmentation running, against the oracle's reseed()."""
+    topo, tables = load_topology("us14_3-paths_6-modulations"), load_phy_tables("us14_k3")
+    kw = dict(load=1400, mean_service_holding_time=25, episode_length=200, seed=10, grooming=True, defrag_period=10, number_moves=10)
+    env = make_env(topo, tables, kw, 4)
+    outs = ("act_path", "channels", "accepted", "arrival", "request")
+    parts = [env.run("bmfa", 130, outputs=outs, auto_reset=True)]
+    env.reseed(901)
+    parts.append(env.run("bmfa", 270, outputs=outs, auto_reset=True))
+    for i in range(4):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=10 + i)
+        op = [o.run("bmfa", 130, reset_on_done=True)]
+        o.reseed(901 + i)
+        op.append(o.run("bmfa", 270, reset_on_done=True))
+        for a, b in zip(parts, op):
+            assert np.array_equal(a["act_path"][:, i], b["act_path"]), i
+            assert np.array_equal(a["channels"][:, i, :12].astype(np.int32), b["channels"]), i
+            assert np.array_equal(a["accepted"][:, i], b["accepted"]) and np.array_equal(a["arrival"][:, i], b["arrival"]), i
+            assert np.array_equal(a["request"][:, i, 3], b["bit_rate"]), i
+        assert np.array_equal(env.available_channels()[i], o.available_channels()), i
+        o.close()
+    env.close()

@@ -433,3 +433,32 @@ def test_random_configurations_cross_check(step_kernel):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["configs_checked"] == 12
+
+
+def test_reseed_between_launches_vs_oracle(nsfnet, device_log_in_oracle, step_kernel):
+    """orlg_reseed: a fresh generator for every environment between two launches -- pending requests kept, arrivals
+    pre-generated from the old generator dropped -- against the oracle's reseed() (all five draws from the new generator: NOT
+    the reference's seed(), whose bit-rate draw stays with the old generator: include/orlg.h, tests/test_oracle_golden.py)."""
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=1000, seed=10)
+    B = 6
+    outs = ("act_path", "act_slot", "accepted", "arrival", "holding", "request")
+    env = make_batched(nsfnet, kw, B, step_kernel=step_kernel)
+    parts = [env.run("sap_ff", 40, outputs=outs)]
+    env.reseed(77)
+    parts.append(env.run("sap_ff", 150, outputs=outs))
+    env.reseed(seeds=np.arange(500, 500 + B, dtype=np.uint64) * 3)
+    parts.append(env.run("sap_ff", 60, outputs=outs))
+    for i in range(B):
+        o = oracle_env_from_kwargs(nsfnet, kw, seed=10 + i)
+        op = [o.run("sap_ff", 40)]
+        o.reseed(77 + i)
+        op.append(o.run("sap_ff", 150))
+        o.reseed((500 + i) * 3)
+        op.append(o.run("sap_ff", 60))
+        for a, b in zip(parts, op):
+            for f in ("act_path", "act_slot", "accepted", "arrival", "holding"):
+                assert np.array_equal(a[f][:, i], b[f]), (f, i)
+            assert np.array_equal(a["request"][:, i, 1], b["src"]) and np.array_equal(a["request"][:, i, 3], b["bit_rate"]), i
+        assert np.array_equal(env.available_slots()[i], o.available_slots()), i
+        o.close()
+    env.close()

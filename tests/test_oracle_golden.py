@@ -113,3 +113,21 @@ def test_oracle_asan(nsfnet):
     env = dict(os.environ, LD_PRELOAD=asan[0], ASAN_OPTIONS="detect_leaks=0")
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
+
+
+def test_oracle_seed_between_steps_vs_reference():
+    """OpticalNetworkEnv.seed called between two steps (optical_network_env.py:266-271): the fixture is the reference's own run
+    (make_golden.py::gen_seed: seed(77) before step 40, seed() -- the default 41 -- before step 80); the oracle's seed() must
+    give the same requests, times and decisions bit for bit."""
+    z, meta = load_golden("seed_rmsa_nsfnet_s10")
+    topo = load_topology(meta["topology"])
+    o = oracle_env_from_kwargs(topo, meta["env_kwargs"])
+    parts = []
+    for t0, t1, sd in ((0, 40, "keep"), (40, 80, 77), (80, 120, None)):
+        if sd != "keep":
+            o.seed(sd)
+        parts.append(o.run("sap_ff", t1 - t0))
+    for f_ in ("src", "dst", "bit_rate", "arrival", "holding", "act_path", "act_slot", "accepted"):
+        got = np.concatenate([p[f_] for p in parts])
+        assert np.array_equal(got, z[f_]), f_
+    o.close()
