@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--queue-capacity", type=int, default=0, help="release-queue slots per environment (0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true", help="headline only")
+    ap.add_argument("--no-pcie-loop", action="store_true", help="DeepRMSA record without the PCIe-inclusive agent loops (profiling: "
+                    "their quarter-batch launches would be mistaken for the record's own)")
     ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "phy_gn", "deeprmsa"],
                     help="run one workload only (profiling)")
     ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
@@ -326,67 +328,70 @@ def deeprmsa_record(clock, args):
     for a, b, c in evs:
         ks.append(a.elapsed_time(b)); ko.append(b.elapsed_time(c))
     step_kernel = env.last_kernel()
-    # the agent loop as an SB3 agent pays it (PCIe-inclusive; never `value`).  (a) the plain form: actions from pageable host
-    # memory, float64 observations copied back into pageable memory, one blocking round trip per step.
-    acts = np.zeros(B, np.int32)
-    obs_h = np.zeros((B, env.obs_dim), np.float64)
-    for _ in range(20):
-        env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
-        env.observation(out=obs_h)
-    n_pcie = 200
-    clock.barrier()
-    t0 = time.perf_counter()
-    for _ in range(n_pcie):
-        env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
-        env.observation(out=obs_h)
-    clock.barrier()
-    el_pcie = time.perf_counter() - t0
-    # (b) the same loop as an asynchronous vector environment runs it: float32 observations (what the agent's network takes),
-    # pinned host buffers, the batch in four parts on four streams -- the agent works on one part's observations while the
-    # others step, so the D2H of one part overlaps the H2D / step / observation build of the others (tools/exp_pcie_loop.py:
-    # whole batch 122 M, halves 129 M, quarters 206 M env-steps/s; the host's issue cost, ~40 us per part, bounds it from there)
-    PARTS = 4
-    halves = []
-    for h in range(PARTS):
-        e2 = BatchedDeepRMSAEnv(topo, B // PARTS, num_spectrum_resources=320, j=1, mean_service_holding_time=7.5,
-                                mean_service_inter_arrival_time=1 / 12.0, node_request_probabilities=DEEPRMSA_NODE_PROBS,
-                                episode_length=50, seed=10 + h * (B // PARTS))
-        st = torch.cuda.Stream(device=clock.dev)
-        e2.set_stream(st.cuda_stream)
-        halves.append(dict(env=e2, st=st, ev=torch.cuda.Event(),
-                           acts_h=torch.zeros(B // PARTS, dtype=torch.int32).pin_memory(),
-                           obs_h=torch.empty((B // PARTS, env.obs_dim), dtype=torch.float32).pin_memory()))
+    el_pcie = el_pipe = 1.0
+    n_pcie = n_pipe = 1
+    if not args.no_pcie_loop:
+        # the agent loop as an SB3 agent pays it (PCIe-inclusive; never `value`).  (a) the plain form: actions from pageable host
+        # memory, float64 observations copied back into pageable memory, one blocking round trip per step.
+        acts = np.zeros(B, np.int32)
+        obs_h = np.zeros((B, env.obs_dim), np.float64)
+        for _ in range(20):
+            env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
+            env.observation(out=obs_h)
+        n_pcie = 200
+        clock.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_pcie):
+            env.run("deeprmsa_external", 1, actions=acts, auto_reset=True)
+            env.observation(out=obs_h)
+        clock.barrier()
+        el_pcie = time.perf_counter() - t0
+        # (b) the same loop as an asynchronous vector environment runs it: float32 observations (what the agent's network takes),
+        # pinned host buffers, the batch in four parts on four streams -- the agent works on one part's observations while the
+        # others step, so the D2H of one part overlaps the H2D / step / observation build of the others (tools/exp_pcie_loop.py:
+        # whole batch 122 M, halves 129 M, quarters 206 M env-steps/s; the host's issue cost, ~40 us per part, bounds it from there)
+        PARTS = 4
+        halves = []
+        for h in range(PARTS):
+            e2 = BatchedDeepRMSAEnv(topo, B // PARTS, num_spectrum_resources=320, j=1, mean_service_holding_time=7.5,
+                                    mean_service_inter_arrival_time=1 / 12.0, node_request_probabilities=DEEPRMSA_NODE_PROBS,
+                                    episode_length=50, seed=10 + h * (B // PARTS))
+            st = torch.cuda.Stream(device=clock.dev)
+            e2.set_stream(st.cuda_stream)
+            halves.append(dict(env=e2, st=st, ev=torch.cuda.Event(),
+                               acts_h=torch.zeros(B // PARTS, dtype=torch.int32).pin_memory(),
+                               obs_h=torch.empty((B // PARTS, env.obs_dim), dtype=torch.float32).pin_memory()))
 
-    def issue(hv):
-        # pinned host buffers are used in place (include/orlg.h): the step kernel reads the actions, the observation kernel
-        # writes its rows over the bus -- no staging copies, three host calls per part and step
-        hv["env"].run("deeprmsa_external", 1, actions=hv["acts_h"], auto_reset=True)
-        hv["env"].observation(out=hv["obs_h"])
-        hv["ev"].record(hv["st"])
-    for _ in range(300):
+        def issue(hv):
+            # pinned host buffers are used in place (include/orlg.h): the step kernel reads the actions, the observation kernel
+            # writes its rows over the bus -- no staging copies, three host calls per part and step
+            hv["env"].run("deeprmsa_external", 1, actions=hv["acts_h"], auto_reset=True)
+            hv["env"].observation(out=hv["obs_h"])
+            hv["ev"].record(hv["st"])
+        for _ in range(300):
+            for hv in halves:
+                issue(hv)
+        torch.cuda.synchronize(clock.dev)
+        n_pipe = 1000
+        clock.barrier()
+        t0 = time.perf_counter()
         for hv in halves:
             issue(hv)
-    torch.cuda.synchronize(clock.dev)
-    n_pipe = 1000
-    clock.barrier()
-    t0 = time.perf_counter()
-    for hv in halves:
-        issue(hv)
-    for _ in range(n_pipe - 1):
+        for _ in range(n_pipe - 1):
+            for hv in halves:
+                hv["ev"].synchronize()     # this half's observations are in host memory: the agent would write its actions now
+                issue(hv)
+        torch.cuda.synchronize(clock.dev)
+        el_pipe = time.perf_counter() - t0
         for hv in halves:
-            hv["ev"].synchronize()     # this half's observations are in host memory: the agent would write its actions now
-            issue(hv)
-    torch.cuda.synchronize(clock.dev)
-    el_pipe = time.perf_counter() - t0
-    for hv in halves:
-        hv["env"].close()
+            hv["env"].close()
     red, _ = env.reduce_counters()
     W = env.words_per_link
     obs_dim = env.obs_dim
     env.close()
     A = algorithmic_bytes_per_env_step(topo, W, extra=8 * obs_dim)
     kernel_ms = float(np.mean(ks)) + float(np.mean(ko))
-    return {"value": B * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": 1,
+    rec = {"value": B * steps / elapsed, "unit": "env steps/s", "batch": B, "env_steps_per_launch_per_env": 1,
             "steps_timed": steps, "timed_region_s": elapsed, "ms_per_step": elapsed * 1e3 / steps,
             "step_kernel": step_kernel.split(" ")[0], "launch": step_kernel, "observation_kernel": "orlg_deeprmsa_obs_kernel<%d>" % W,
             "kernel_ms_step": float(np.mean(ks)), "kernel_ms_observation": float(np.mean(ko)), "obs_dim": obs_dim,
@@ -397,6 +402,9 @@ def deeprmsa_record(clock, args):
                                                        "what": "one blocking round trip per step, %d B/env float64 D2H" % (8 * obs_dim)}},
             "service_blocking_rate": (red["services_processed"] - red["services_accepted"]) / max(1, red["services_processed"]),
             "roofline": roofline_block("deeprmsa", step_kernel.split(" ")[0] + " + orlg_deeprmsa_obs_kernel<%d>" % W, kernel_ms, A, B, B)}
+    if args.no_pcie_loop:
+        rec.pop("pcie_inclusive")
+    return rec
 
 
 def cpu_baseline(topo, seconds=10.0):

@@ -94,7 +94,7 @@ def main():
     os.makedirs(scratch)
     os.environ["TMPDIR"] = "/tmp"
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--only", args.name, "--steps", str(args.steps), "--warmup", "1",
-             "--no-cpu-baseline"] + args.extra.split()
+             "--no-cpu-baseline"] + (["--no-pcie-loop"] if args.name == "deeprmsa" else []) + args.extra.split()
     # the un-profiled line first (never compare a profiled arm with an un-profiled one: both are recorded)
     run(bench, os.path.join(scratch, "bench.json"))
     bench_line = json.loads([ln for ln in open(os.path.join(scratch, "bench.json")) if ln.startswith("{")][-1])
