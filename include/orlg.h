@@ -55,14 +55,15 @@ typedef struct orlg_topology {
 /* Constructor kwargs of RMSAEnv / DeepRMSAEnv (optical_rl_gym/envs/rmsa_env.py:29-53,
  * deeprmsa_env.py:10-32) after the host has turned weights into the cumulative tables CPython's
  * random.choices builds (optical_network_env.py:197-206).
- * bit_rate_selection = "discrete" only.  "continuous" (rmsa_env.py:95-104, 655-659) draws the bit rate with rng.randint,
- * i.e. CPython's _randbelow: rejection sampling that consumes a data-dependent number of MT19937 words per request.  The
- * arrival generator here produces 64 requests at a time, request j from words [10 j, 10 j + 10) of the stream, which needs a
- * fixed draw count per request; the host side refuses "continuous" (NotImplementedError) instead of approximating it. */
+ * bit_rate_selection = "continuous" (rmsa_env.py:95-104, 655-659): bit_rate_cum = NULL, bit_rates = the integers lower ..
+ * higher (at most 256).  The reference draws the rate with rng.randint, i.e. CPython's _randbelow -- getrandbits(k) repeated
+ * until the value is below the width -- which consumes a data-dependent number of MT19937 words per request; the arrival
+ * generator then walks the word stream once to find where every request starts before the lanes compute their requests.
+ * The bit-rate histograms are kept per integer rate (the reference keeps none in this mode). */
 typedef struct orlg_rmsa_config {
     int32_t num_slots;        /* num_spectrum_resources, 1..512 */
     int32_t episode_length;
-    int32_t num_bit_rates;    /* 1..64 */
+    int32_t num_bit_rates;    /* 1..64 (continuous: 1..256) */
     int32_t j;                /* DeepRMSA: blocks per path in action / observation (deeprmsa_env.py:34) */
     int32_t reward_mode;      /* 0: 1/0 (optical_network_env.py:213-214); 1: +1/-1 (deeprmsa_env.py:123-124) */
     int32_t queue_capacity;   /* release-queue slots per env (rounded up to a multiple of 16, at least 64); 0 = pick from the
@@ -73,7 +74,7 @@ typedef struct orlg_rmsa_config {
     double holding_lambda;    /* 1 / mean_service_holding_time (rmsa_env.py:651) */
     double channel_width;     /* GHz per slot, 12.5 (rmsa_env.py:46,708-719) */
     const int32_t *bit_rates;   /* [num_bit_rates] */
-    const double *bit_rate_cum; /* [num_bit_rates] */
+    const double *bit_rate_cum; /* [num_bit_rates]; NULL: bit_rate_selection="continuous" */
     const double *src_cum;      /* [N] */
     const double *dst_cum;      /* [N*N] row s = destination table given source s */
 } orlg_rmsa_config;

@@ -61,9 +61,19 @@ class BatchedRMSAEnv:
                  bit_rate_probabilities=None, node_request_probabilities=None, seed: Optional[int] = None,
                  seeds=None, allow_rejection: bool = False, channel_width: float = 12.5, j: int = 1,
                  reward_mode: int = 0, stats_level: str = "full", queue_capacity: int = 0, device: int = 0,
-                 step_kernel: str = "auto"):
-        if bit_rate_selection != "discrete":
-            raise NotImplementedError("only bit_rate_selection='discrete' runs on the device path")
+                 step_kernel: str = "auto", bit_rate_lower_bound=25, bit_rate_higher_bound=100):
+        if bit_rate_selection not in ("continuous", "discrete"):   # rmsa_env.py:74
+            raise ValueError("bit_rate_selection must be 'continuous' or 'discrete'")
+        self.bit_rate_selection = bit_rate_selection
+        if bit_rate_selection == "continuous":
+            # rmsa_env.py:95-101: rng.randint(lower, higher) -- every integer rate of the range, drawn by rejection on the device
+            lo, hi = int(bit_rate_lower_bound), int(bit_rate_higher_bound)
+            if lo != bit_rate_lower_bound or hi != bit_rate_higher_bound or hi < lo:
+                raise ValueError("bit_rate_lower_bound / bit_rate_higher_bound must be integers, lower <= higher (random.randint)")
+            if hi - lo + 1 > 256:
+                raise ValueError("continuous bit rates: at most 256 integer rates (lower .. higher)")
+            self.bit_rate_lower_bound, self.bit_rate_higher_bound = lo, hi
+            bit_rates, bit_rate_probabilities = list(range(lo, hi + 1)), None
         self.L = _lib.load()
         self.topology = FrozenTopology.from_graph(topology)
         t = self.topology
@@ -111,7 +121,7 @@ class BatchedRMSAEnv:
         cc.holding_lambda = 1 / self.mean_service_holding_time
         cc.channel_width = self.channel_width
         cc.bit_rates = keep(self.bit_rates, np.int32)
-        cc.bit_rate_cum = keep(br_cum, np.float64)
+        cc.bit_rate_cum = keep(br_cum, np.float64) if bit_rate_selection == "discrete" else None   # (NULL: rng.randint)
         cc.src_cum = keep(src_cum, np.float64)
         cc.dst_cum = keep(dst_cum, np.float64)
         seeds_ptr = None

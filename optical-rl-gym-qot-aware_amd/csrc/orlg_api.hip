@@ -446,7 +446,14 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
     if (N < 2 || N > 64) return fail(ORLG_ERR_INVALID, "num_nodes %d not in 2..64", N);
     if (E < 1 || E > 255) return fail(ORLG_ERR_INVALID, "num_links %d not in 1..255", E);
     if (S < 1 || S > 512) return fail(ORLG_ERR_INVALID, "num_slots %d not in 1..512", S);
-    if (NBR < 1 || NBR > 64) return fail(ORLG_ERR_INVALID, "num_bit_rates %d not in 1..64", NBR);
+    // bit_rate_cum == NULL: bit_rate_selection="continuous" -- bit_rates = lower .. higher, one apart, drawn with rng.randint
+    const bool cont = c->bit_rate_cum == nullptr;
+    if (NBR < 1 || NBR > (cont ? 256 : 64)) return fail(ORLG_ERR_INVALID, "num_bit_rates %d not in 1..%d", NBR, cont ? 256 : 64);
+    if (cont) {
+        if (!c->bit_rates) return fail(ORLG_ERR_INVALID, "null argument");
+        for (int b = 1; b < NBR; b++)
+            if (c->bit_rates[b] != c->bit_rates[0] + b) return fail(ORLG_ERR_INVALID, "continuous bit rates must be lower .. higher, one apart");
+    }
     if (t->num_paths < 1 || t->num_paths >= (1 << 14)) return fail(ORLG_ERR_INVALID, "num_paths %d not in 1..16383", t->num_paths);
     int W = (S + 63) / 64;
     if (W == 7) W = 8;  // no W=7 instantiation: pad to 8 words (top word all invalid)
@@ -558,7 +565,11 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
             }
         p.t_nslots = put(ns.data(), ns.size() * 2);
         p.t_bitrates = put(c->bit_rates, (size_t)NBR * 4);
-        p.t_brcum = put(c->bit_rate_cum, (size_t)NBR * 8);
+        {
+            std::vector<double> zc((size_t)NBR, 0.0);   // (continuous: no cumulative weights, the table stays in place)
+            p.t_brcum = put(cont ? zc.data() : c->bit_rate_cum, (size_t)NBR * 8);
+        }
+        p.br_width = cont ? NBR : 0;
         p.t_srccum = put(c->src_cum, (size_t)N * 8);
         p.t_dstcum = put(c->dst_cum, (size_t)N * N * 8);
         if (c->stats_level >= ORLG_STATS_FULL) {

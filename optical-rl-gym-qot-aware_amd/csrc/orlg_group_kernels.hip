@@ -581,9 +581,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 l_mt[lane] = m0; l_mt[lane + 64] = m1;
                 if (lane < 156 - 128) l_mt[lane + 128] = m2;
                 wave_sync();
-                const int got = refill_requests(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
-                                                p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N,
-                                                NBR, p.arrival_lambda, p.holding_lambda, env_s);
+                const int got = p.br_width > 0   // bit_rate_selection="continuous"
+                    ? refill_requests_cont_t<false>(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
+                                                    p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, &idx_s, N, p.br_width,
+                                                    p.arrival_lambda, p.holding_lambda)
+                    : refill_requests(mt_lds, p.ring_iat + (size_t)env_s * ORLG_RING, p.ring_ht + (size_t)env_s * ORLG_RING,
+                                      p.ring_req + (size_t)env_s * ORLG_RING, tb.src_cum, tb.dst_cum, tb.br_cum, &idx_s, N,
+                                      NBR, p.arrival_lambda, p.holding_lambda, env_s);
                 m0 = l_mt[lane]; m1 = l_mt[lane + 64];
                 if (lane < 156 - 128) m2 = l_mt[lane + 128];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's reads of the buffer are done

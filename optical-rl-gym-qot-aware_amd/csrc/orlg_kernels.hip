@@ -310,6 +310,95 @@ DEV int refill_requests(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_
     return refill_requests_t<false>(mt, ring_iat, ring_ht, ring_req, src_cum, dst_cum, br_cum, idx_io, N, NBR, lam_arrival, lam_holding, env);
 }
 
+// bit_rate_selection="continuous" (rmsa_env.py:95-101, 655-659): the bit rate is rng.randint(lower, higher) = lower +
+// _randbelow(width), CPython's _randbelow_with_getrandbits: k = width.bit_length(); r = getrandbits(k) -- one MT19937 word
+// shifted right by 32 - k -- until r < width.  A request then consumes eight words for its four random() values and a
+// VARIABLE number for the bit rate, so request j no longer starts at a known word.  Two phases: (1) one walk over the word
+// stream, wave-uniform, that only looks at the bit-rate words -- where every request starts and which r it accepts (~25
+// instructions per request); (2) lane j computes request j from its eight words like the discrete generator.  A refill
+// stays inside the state's current 624 words; the request that straddles a regeneration is generated alone, word by word.
+// The ring entry holds r (the index into the table of the width bit rates lower .. higher).  Returns count | new index << 8.
+template <bool RING_LDS>
+__device__ __noinline__ int refill_requests_cont_as(orlg_lds_u32 *mt, void *ring_iat_v, void *ring_ht_v, void *ring_req_v,
+                                                    orlg_lds_cf64 *src_cum, orlg_lds_cf64 *dst_cum, int idx, int N, int width,
+                                                    double lam_arrival, double lam_holding) {
+    const int lane = threadIdx.x & 63;
+    const double ylam_arrival = recip_refine(lam_arrival), ylam_holding = recip_refine(lam_holding);
+    const int sh = 32 - (32 - __builtin_clz((unsigned)width));   // 32 - k, k = width.bit_length()
+    auto temper = [](uint32_t y) { y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18); return y; };
+    if (idx >= ORLG_MT_N) { mt_regenerate(mt, lane); idx = 0; }
+    // phase 1: the requests that lie inside [idx, 624)
+    int n = 0, my_off = 0, my_r = 0, off = idx;
+    for (; n < ORLG_RING; ++n) {
+        int w = off + 8;
+        if (w >= ORLG_MT_N) break;
+        int r = 0;
+        bool got = false;
+        while (w < ORLG_MT_N) {
+            r = (int)(temper(mt[w]) >> sh);
+            w += 1;
+            if (r < width) { got = true; break; }
+        }
+        if (!got) break;          // its bit-rate draws run past the state's end
+        if (lane == n) { my_off = off; my_r = r; }
+        off = w;
+    }
+    double u[4];
+    if (n == 0) {
+        // the straddler: word by word through the regeneration, every lane the same values
+        uint32_t wq[8];
+        int r = 0;
+        for (int k = 0;; ++k) {
+            if (off >= ORLG_MT_N) { mt_regenerate(mt, lane); off = 0; }
+            const uint32_t y = temper(mt[off]);
+            off += 1;
+            if (k < 8) { wq[k] = y; continue; }
+            r = (int)(y >> sh);
+            if (r < width) break;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = ((double)(wq[2 * q] >> 5) * 67108864.0 + (double)(wq[2 * q + 1] >> 6)) * (1.0 / 9007199254740992.0);
+        my_r = r;
+        n = 1;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t a = lane < n ? temper(mt[my_off + 2 * q]) : 0u, b = lane < n ? temper(mt[my_off + 2 * q + 1]) : 0u;
+            u[q] = ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+        }
+    }
+    idx = off;
+    const double iat = div_by(-orlg_log(1.0 - u[0]), lam_arrival, ylam_arrival);
+    const double ht = div_by(-orlg_log(1.0 - u[1]), lam_holding, ylam_holding);
+    int src = 0, dst = 0;
+    {
+        const double x = u[2] * (src_cum[N - 1] + 0.0);
+        for (int i = 0; i < N - 1; ++i) src += src_cum[i] <= x ? 1 : 0;
+    }
+    {
+        orlg_lds_cf64 *row = dst_cum + src * N;
+        const double x = u[3] * (row[N - 1] + 0.0);
+        for (int i = 0; i < N - 1; ++i) dst += row[i] <= x ? 1 : 0;
+    }
+    const double o_iat = lane < n ? iat : 0.0, o_ht = lane < n ? ht : 0.0;
+    const uint32_t o_rq = lane < n ? ((uint32_t)src | ((uint32_t)dst << 8) | ((uint32_t)my_r << 16)) : 0u;
+    if (RING_LDS) {
+        ((orlg_lds_f64 *)ring_iat_v)[lane] = o_iat; ((orlg_lds_f64 *)ring_ht_v)[lane] = o_ht; ((orlg_lds_u32 *)ring_req_v)[lane] = o_rq;
+    } else {
+        ((orlg_glb_f64 *)ring_iat_v)[lane] = o_iat; ((orlg_glb_f64 *)ring_ht_v)[lane] = o_ht; ((orlg_glb_u32 *)ring_req_v)[lane] = o_rq;
+    }
+    wave_sync();
+    return n | (idx << 8);
+}
+template <bool RING_LDS>
+DEV int refill_requests_cont_t(uint32_t *mt, double *ring_iat, double *ring_ht, uint32_t *ring_req, const double *src_cum,
+                               const double *dst_cum, int *idx_io, int N, int width, double lam_arrival, double lam_holding) {
+    const int r = refill_requests_cont_as<RING_LDS>((orlg_lds_u32 *)mt, ring_iat, ring_ht, ring_req, (orlg_lds_cf64 *)src_cum,
+                                                    (orlg_lds_cf64 *)dst_cum, *idx_io, N, width, lam_arrival, lam_holding);
+    *idx_io = r >> 8;
+    return r & 0xff;
+}
+
 // ---------------------------------------------------------------------------------------- first fit
 // x[w]: wave-uniform free bitmap of one path (AND over its links).  Lane l of word w owns slot 64w+l
 // and computes the length of the free run starting there.
@@ -1138,8 +1227,12 @@ DEV void rmsa_body(const OrlgParams &p) {
                 }
                 ring_dirty = true;
                 ring_in_lds = true;
-                ring_cnt = refill_requests_t<true>(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
-                                           &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda, env);
+                if (p.br_width > 0)   // bit_rate_selection="continuous"
+                    ring_cnt = refill_requests_cont_t<true>(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, &mt_idx, N,
+                                                            p.br_width, p.arrival_lambda, p.holding_lambda);
+                else
+                    ring_cnt = refill_requests_t<true>(wv.mt, wv.ring_iat, wv.ring_ht, wv.ring_req, tb.src_cum, tb.dst_cum, tb.br_cum,
+                                                       &mt_idx, N, NBR, p.arrival_lambda, p.holding_lambda, env);
                 ring_pos = 0;
                 SEC(7);
             }

@@ -102,6 +102,7 @@ class RMSAEnv:
                                          mean_service_holding_time=mean_service_holding_time,
                                          num_spectrum_resources=num_spectrum_resources,
                                          bit_rate_selection=bit_rate_selection, bit_rates=bit_rates,
+                                         bit_rate_lower_bound=bit_rate_lower_bound, bit_rate_higher_bound=bit_rate_higher_bound,
                                          bit_rate_probabilities=bit_rate_probabilities,
                                          node_request_probabilities=node_request_probabilities, seed=seed,
                                          allow_rejection=allow_rejection, channel_width=channel_width, device=device)
@@ -124,8 +125,11 @@ class RMSAEnv:
         self.channel_width = batched.channel_width
         self.allow_rejection = batched.allow_rejection
         self.reject_action = batched.reject_action
-        self.bit_rate_selection = "discrete"
-        self.bit_rates = list(batched.bit_rates)
+        self.bit_rate_selection = getattr(batched, "bit_rate_selection", "discrete")
+        if self.bit_rate_selection == "discrete":   # (rmsa_env.py:103-111: the attribute exists in this mode only)
+            self.bit_rates = list(batched.bit_rates)
+        else:
+            self.bit_rate_lower_bound, self.bit_rate_higher_bound = batched.bit_rate_lower_bound, batched.bit_rate_higher_bound
         self.load = batched.load
         self.mean_service_holding_time = batched.mean_service_holding_time
         self.mean_service_inter_arrival_time = batched.mean_service_inter_arrival_time
@@ -282,6 +286,8 @@ class RMSAEnv:
         # np.mean over the links, evaluated on the device at the reference's point in the step
         info["avg_link_compactness"] = avg_link_compactness
         info["avg_link_utilization"] = avg_link_utilization
+        if self.bit_rate_selection != "discrete":   # rmsa_env.py:276, 327: the per-rate keys exist in discrete mode only
+            return info
         h = b.bit_rate_hist()
         blocking = {}
         for k, rate in enumerate(self.bit_rates):

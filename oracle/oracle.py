@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-MAX_BIT_RATES = 64
+MAX_BIT_RATES = 256
 
 POLICY = {"sp_ff": 0, "sap_ff": 1, "llp_ff": 2, "deeprmsa_sp_ff": 3, "deeprmsa_sap_ff": 4, "external": -1,
           "deeprmsa_external": 5, "path_ff_external": 6}
@@ -148,7 +148,7 @@ class OracleEnv:
         c.j, c.reward_mode = int(j), int(reward_mode)
         c.arrival_lambda, c.holding_lambda, c.channel_width = float(arrival_lambda), float(holding_lambda), float(channel_width)
         c.bit_rates = _ptr(keep(bit_rates, np.int32))
-        c.bit_rate_cum = _ptr(keep(bit_rate_cum, np.float64))
+        c.bit_rate_cum = _ptr(keep(bit_rate_cum, np.float64)) if bit_rate_cum is not None else None   # None: continuous
         c.src_cum = _ptr(keep(src_cum, np.float64))
         c.dst_cum = _ptr(keep(dst_cum, np.float64))
         self.N, self.E, self.K, self.S, self.j = t.num_nodes, t.num_links, t.k_paths, int(num_slots), int(j)

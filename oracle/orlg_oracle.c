@@ -299,7 +299,9 @@ static void next_service(orc_env *e) {
     double ht = py_expovariate(&e->rng, e->cfg.holding_lambda);
     int src = py_choice_cum(&e->rng, e->cfg.src_cum, e->N);
     int dst = py_choice_cum(&e->rng, e->cfg.dst_cum + (size_t)src * e->N, e->N);
-    int bri = py_choice_cum(e->split ? &e->rng_br : &e->rng, e->cfg.bit_rate_cum, e->cfg.num_bit_rates);
+    /* rmsa_env.py:655-659: continuous -> rng.randint(lower, higher) (the partial is bound like the discrete one: orc_seed) */
+    int bri = e->cfg.bit_rate_cum ? py_choice_cum(e->split ? &e->rng_br : &e->rng, e->cfg.bit_rate_cum, e->cfg.num_bit_rates)
+                                  : (int)py_randbelow(e->split ? &e->rng_br : &e->rng, (uint32_t)e->cfg.num_bit_rates);
 
     service *s = (service *)calloc(1, sizeof(service));
     s->service_id = (int32_t)e->c.episode_services_processed;

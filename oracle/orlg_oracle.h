@@ -46,7 +46,8 @@ typedef struct orc_config {
     double holding_lambda;   /* 1 / mean_service_holding_time        (rmsa_env.py:651) */
     double channel_width;    /* 12.5 */
     const int32_t *bit_rates;   /* [num_bit_rates] */
-    const double *bit_rate_cum; /* [num_bit_rates] list(accumulate(bit_rate_probabilities)) */
+    const double *bit_rate_cum; /* [num_bit_rates] list(accumulate(bit_rate_probabilities)); NULL: bit_rate_selection="continuous",
+                                 * bit_rates = lower .. higher and the rate is rng.randint(lower, higher) (rmsa_env.py:95-101, 655-659) */
     const double *src_cum;      /* [N]   list(accumulate(node_request_probabilities)) */
     const double *dst_cum;      /* [N*N] row s: accumulate(p with p[s]=0, renormalised) (optical_network_env.py:201-206) */
 } orc_config;
@@ -56,7 +57,7 @@ enum { ORC_POLICY_SP_FF = 0, ORC_POLICY_SAP_FF = 1, ORC_POLICY_LLP_FF = 2,
        ORC_POLICY_DEEPRMSA_EXTERNAL = 5, /* orc_run only: actions_in[i] is a Discrete(k*j) action */
        ORC_POLICY_PATH_FF_EXTERNAL = 6   /* orc_run only: actions_in[i] is a path index, PathOnlyFirstFitAction (rmsa_env.py:974-1008) */ };
 
-#define ORC_MAX_BIT_RATES 64
+#define ORC_MAX_BIT_RATES 256
 
 typedef struct orc_request {
     int32_t service_id, src, dst, bit_rate;

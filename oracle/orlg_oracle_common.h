@@ -87,6 +87,15 @@ ORC_UNUSED static double py_random(py_rng *r) {
  * orc_set_log_fn() lets a test substitute another log (the product's host build of its device log) so
  * that the oracle and the device can be compared bit for bit on every float as well. */
 extern double (*orc_g_log)(double);
+/* random.randrange / randint over `n` values: Random._randbelow_with_getrandbits (Lib/random.py): k = n.bit_length();
+ * r = getrandbits(k) while r >= n; getrandbits(k <= 32) = genrand_uint32() >> (32 - k) (_randommodule.c) */
+ORC_UNUSED static uint32_t py_randbelow(py_rng *r, uint32_t n) {
+    int k = 0;
+    for (uint32_t t = n; t; t >>= 1) k++;
+    uint32_t v = mt_genrand(r) >> (32 - k);
+    while (v >= n) v = mt_genrand(r) >> (32 - k);
+    return v;
+}
 ORC_UNUSED static double py_expovariate(py_rng *r, double lambd) { return -orc_g_log(1.0 - py_random(r)) / lambd; }
 
 /* Lib/random.py choices(k=1) with cumulative weights: bisect_right(cum, random()*total, 0, n-1) */

@@ -46,8 +46,13 @@ def oracle_env_from_kwargs(topo, env_kwargs, seed=None, j=1, reward_mode=0, asan
 
     kw = dict(env_kwargs)
     bit_rates = kw.get("bit_rates", DEFAULT_BIT_RATES)
+    cont = kw.get("bit_rate_selection", "discrete") == "continuous"
+    if cont:   # rmsa_env.py:95-101: rng.randint(lower, higher)
+        bit_rates = list(range(int(kw.get("bit_rate_lower_bound", 25)), int(kw.get("bit_rate_higher_bound", 100)) + 1))
     _, src_cum, dst_cum, br_cum = selection_tables(kw.get("node_request_probabilities"),
-                                                   kw.get("bit_rate_probabilities"), topo.num_nodes, bit_rates)
+                                                   None if cont else kw.get("bit_rate_probabilities"), topo.num_nodes, bit_rates)
+    if cont:
+        br_cum = None
     load, ht = kw.get("load", 10), kw.get("mean_service_holding_time", 10800.0)
     # optical_network_env.py:127-129 ; rmsa_env.py:646-651
     mean_iat = 1 / float(load / float(ht))

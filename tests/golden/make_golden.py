@@ -221,7 +221,7 @@ def run_rmsa_trace(topo, env_kwargs, policy, n_steps, reset_on_done, rec_links=T
             network_compactness_difference=float(info["network_compactness_difference"]),
             avg_link_compactness=float(info["avg_link_compactness"]),
             avg_link_utilization=float(info["avg_link_utilization"]),
-            fairness=float(info["fairness"]),
+            fairness=float(info.get("fairness", 0.0)),   # (discrete mode only: rmsa_env.py:327-332)
             free_total=int(av.sum()), occ_crc=occ_crc(av), current_time=env.current_time,
             graph_throughput=float(env.topology.graph["throughput"]),
             graph_compactness=float(env.topology.graph["compactness"]),
@@ -237,16 +237,17 @@ def run_rmsa_trace(topo, env_kwargs, policy, n_steps, reset_on_done, rec_links=T
     out["final_link_last_update"] = np.array([env.topology[a][b]["last_update"] for a, b in edges])
     out["final_available_slots"] = np.packbits(
         env.topology.graph["available_slots"].astype(np.uint8), axis=1, bitorder="little")
-    out["final_bit_rate_requested_hist"] = np.array(
-        [env.bit_rate_requested_histogram[b] for b in env.bit_rates], dtype=np.int64)
-    out["final_bit_rate_provisioned_hist"] = np.array(
-        [env.bit_rate_provisioned_histogram[b] for b in env.bit_rates], dtype=np.int64)
-    out["final_episode_bit_rate_requested_hist"] = np.array(
-        [env.episode_bit_rate_requested_histogram[b] for b in env.bit_rates], dtype=np.int64)
-    out["final_episode_bit_rate_provisioned_hist"] = np.array(
-        [env.episode_bit_rate_provisioned_histogram[b] for b in env.bit_rates], dtype=np.int64)
-    # last step's per-bit-rate blocking (info keys bit_rate_blocking_<rate>)
-    out["final_bit_rate_blocking"] = np.array([info[f"bit_rate_blocking_{b}"] for b in env.bit_rates])
+    if env.bit_rate_selection == "discrete":   # the histograms and the per-rate info keys exist in this mode only
+        out["final_bit_rate_requested_hist"] = np.array(
+            [env.bit_rate_requested_histogram[b] for b in env.bit_rates], dtype=np.int64)
+        out["final_bit_rate_provisioned_hist"] = np.array(
+            [env.bit_rate_provisioned_histogram[b] for b in env.bit_rates], dtype=np.int64)
+        out["final_episode_bit_rate_requested_hist"] = np.array(
+            [env.episode_bit_rate_requested_histogram[b] for b in env.bit_rates], dtype=np.int64)
+        out["final_episode_bit_rate_provisioned_hist"] = np.array(
+            [env.episode_bit_rate_provisioned_histogram[b] for b in env.bit_rates], dtype=np.int64)
+        # last step's per-bit-rate blocking (info keys bit_rate_blocking_<rate>)
+        out["final_bit_rate_blocking"] = np.array([info[f"bit_rate_blocking_{b}"] for b in env.bit_rates])
     # the request pending after the last step (what the next heuristic call would see)
     s = env.current_service
     out["pending"] = np.array([s.source_id, s.destination_id, s.bit_rate, s.service_id], dtype=np.int64)
@@ -275,6 +276,12 @@ RMSA_CASES = [
           bit_rates=[25, 50, 75, 100], bit_rate_probabilities=[0.4, 0.3, 0.2, 0.1],
           num_spectrum_resources=100, episode_length=50), "sap_ff", 1000, True),
     ("rmsa_jpn12k5_s3_sapff", "jpn12_5-paths_6-modulations", dict(seed=3, load=120), "sap_ff", 1000, False),
+    ("rmsa_nsfnet_s10_sapff_continuous", "nsfnet_chen_5-paths_6-modulations",
+     dict(seed=10, load=300, num_spectrum_resources=100, bit_rate_selection="continuous", bit_rate_lower_bound=25,
+          bit_rate_higher_bound=100, episode_length=200), "sap_ff", 1500, True),
+    ("rmsa_us14_s4_llpff_continuous", "us14_3-paths_6-modulations",
+     dict(seed=4, load=150, num_spectrum_resources=128, bit_rate_selection="continuous", bit_rate_lower_bound=100,
+          bit_rate_higher_bound=300), "llp_ff", 800, False),
     ("rmsa_us14_s5_llpff", "us14_3-paths_6-modulations", dict(seed=5, load=60, num_spectrum_resources=192),
      "llp_ff", 1000, False),
     ("rmsa_spn_s2_sapff", "spn_3-paths_6-modulations", dict(seed=2, load=400, num_spectrum_resources=64),

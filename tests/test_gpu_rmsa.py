@@ -170,9 +170,10 @@ def test_golden_case_vs_reference_and_oracle(case, device_log_in_oracle):
         np.testing.assert_allclose(ls["utilization"][0], z["final_link_utilization"], rtol=1e-11)
         np.testing.assert_allclose(ls["external_fragmentation"][0], z["final_link_external_fragmentation"], rtol=1e-11)
         np.testing.assert_allclose(ls["compactness"][0], z["final_link_compactness"], rtol=1e-11)
-        h = env.bit_rate_hist()
-        assert np.array_equal(h["requested"][0], z["final_bit_rate_requested_hist"])
-        assert np.array_equal(h["provisioned"][0], z["final_bit_rate_provisioned_hist"])
+        if "final_bit_rate_requested_hist" in z.files:   # (bit_rate_selection="continuous": the reference keeps no histograms)
+            h = env.bit_rate_hist()
+            assert np.array_equal(h["requested"][0], z["final_bit_rate_requested_hist"])
+            assert np.array_equal(h["provisioned"][0], z["final_bit_rate_provisioned_hist"])
     env.close()
 
 
