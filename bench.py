@@ -137,7 +137,8 @@ def load_pmc(key):
 ROOFLINE_NOTE = ("every roofline block: bound/achieved/frac = SURVEY 8(d) algorithmic bytes per env-step x env-steps per launch / mean "
                  "launch time (HIP events on the kernel's stream), peak 8 TB/s; traffic = HBM bytes per launch from the FETCH_SIZE "
                  "(x2, gfx950) + WRITE_SIZE passes in profiles/pmc.json; the state lives in LDS for a whole launch, so what binds is "
-                 "in valu_issue (wave-instructions/s against 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; valu_busy from the same counters)")
+                 "in valu_issue (wave-instructions/s against 256 CU x 4 SIMD x 2.4 GHz / 4 cycles = 614.4 G/s; valu_busy from the same "
+                 "counters); sub-record blocks share bound / peak / unit with this one and come from profiles/r03_<workload>_summary.json")
 
 
 def roofline_block(key, kernel, kernel_ms, A, env_steps_per_launch, batch):
@@ -447,14 +448,23 @@ def cpu_baseline(topo, seconds=10.0):
             "note": "C oracle only; the reference (Python + NumPy) runs 242 env-steps/s on one core (BASELINE.md 2) and cannot travel"}
 
 
+# keys of a SUB-record that repeat what the line already says once (the unit, the 8 TB/s peak, the kernel's name inside "launch",
+# the VALU peak of ROOFLINE_NOTE, the profile a counter block came from = profiles/r03_<workload>_summary.json)
+SUB_DROP = {"unit", "step_kernel", "timed_region_s", "launches_timed", "launches_warmup", "steps_timed", "peak", "kernel",
+            "env_steps_per_launch", "bound", "source", "queue_overflow", "observation_kernel", "obs_dim", "what"}
+
+
 def compact(x, keep=("value", "ms_per_step", "timed_region_s")):
-    """Floats to 6 significant digits (the headline's value / ms_per_step / timed_region_s stay as measured) and no null
-    entries below the top level: the whole line, every sub-record included, has to fit the tail the driver keeps."""
-    def walk(v, top):
+    """Floats to 6 significant digits (the headline's value / ms_per_step / timed_region_s stay as measured), no null entries
+    below the top level and no repeated constants inside the sub-records: the whole line, every sub-record included, has to
+    fit the 8 KB tail the driver keeps."""
+    def walk(v, top, sub=False):
         if isinstance(v, dict):
-            return {k: (vv if (top and k in keep) else walk(vv, False)) for k, vv in v.items() if top or vv is not None}
+            if top:
+                return {k: (vv if k in keep else walk(vv, False, k == "sub_records")) for k, vv in v.items()}
+            return {k: walk(vv, False, sub) for k, vv in v.items() if vv is not None and not (sub and k in SUB_DROP)}
         if isinstance(v, (list, tuple)):
-            return [walk(e, False) for e in v]
+            return [walk(e, False, sub) for e in v]
         if isinstance(v, float):
             return float("%.6g" % v)
         return v
