@@ -467,3 +467,44 @@ def test_phy_reseed_between_launches_vs_oracle(device_log_in_oracle):
         assert np.array_equal(env.available_channels()[i], o.available_channels()), i
         o.close()
     env.close()
+
+
+@pytest.mark.parametrize("policy,defrag", [("bmfa", None), ("bmfa_rss", None), ("sapff", "cut"), ("bmfa", "rss"), ("faff", "cut")])
+def test_phy_large_network_general_paths(policy, defrag, device_log_in_oracle):
+    """SPN (30 nodes, 56 links) is beyond the fast paths' structural limits: no node-degree vectors (N > 16), no
+    32-bit link-axis columns and no incremental per-step totals (E > 32) -- the cut metric walks the adjacency lists, the RSS
+    metric the link axis, number_cuts_total / rss_total_metric are rebuilt from all columns every step, the defragmentation
+    scores through the same general code.  Synthetic QoT tables (the reference ships none for SPN), device vs oracle."""
+    topo = load_topology("spn_3-paths_6-modulations")
+    rng = np.random.default_rng(3)
+    n = topo.num_nodes
+    pairs = np.array([(a + 1, b + 1) for a in range(n) for b in range(a + 1, n)], np.int32)
+    mod = rng.integers(1, 7, size=(len(pairs), 268, 3)).astype(np.uint8)
+    gsnr = rng.uniform(5.0, 25.0, size=mod.shape)
+    tables = (pairs, mod, gsnr)
+    kw = dict(load=2500, mean_service_holding_time=25, episode_length=150, seed=4, grooming=policy != "sapff")
+    if defrag:
+        kw.update(defrag_period=9, number_moves=7, metric=defrag)
+    env = make_env(topo, tables, kw, 3)
+    assert not env.node_vectors
+    outs = ("act_path", "channels", "channels_used", "accepted", "number_cuts_total", "rss_total_metric", "defrag_counters")
+    parts = [env.run(policy, k, outputs=outs, auto_reset=True) for k in (180, 2, 120)]
+    tr = {k: np.concatenate([q[k] for q in parts]) for k in outs}
+    av, cnt = env.available_channels(), env.counters()
+    assert env.episode_stats()["queue_overflow"].max() == 0
+    for i in range(3):
+        o = phy_oracle_from_kwargs(topo, tables, kw, seed=4 + i)
+        ot = o.run(policy, 302, reset_on_done=True)
+        assert np.array_equal(tr["act_path"][:, i], ot["act_path"]), i
+        assert np.array_equal(tr["channels"][:, i, :12].astype(np.int32), ot["channels"]), i
+        assert np.array_equal(tr["channels_used"][:, i, :12].astype(np.float64), ot["ch_used"]), i
+        assert np.array_equal(tr["number_cuts_total"][:, i], ot["number_cuts_total"]), i
+        assert np.array_equal(tr["rss_total_metric"][:, i], ot["rss_total_metric"]), i
+        dc = tr["defrag_counters"][:, i].astype(np.int64)
+        assert np.array_equal(dc[:, 1], ot["num_moves_groom"]) and np.array_equal(dc[:, 0] / 2 + dc[:, 1], ot["num_moves"]), i
+        assert np.array_equal(av[i], o.available_channels()), i
+        assert cnt["services_accepted"][i] == o.counters()["services_accepted"], i
+        assert env.channel_state(i) == o.channel_state(), i
+        o.close()
+    assert tr["accepted"].mean() > 0.5
+    env.close()

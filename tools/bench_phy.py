@@ -23,12 +23,23 @@ def main():
     ap.add_argument("--moves", type=int, default=10, help="number_moves with --defrag")
     ap.add_argument("--period", type=int, default=10, help="defrag_period with --defrag")
     ap.add_argument("--queue", type=int, default=0, help="queue_capacity (0 = from the load)")
+    ap.add_argument("--topology", default="us14_3-paths_6-modulations",
+                    help="another fixture (e.g. spn_3-paths_6-modulations: 30 nodes / 56 links, the structural limits of DESIGN 6) runs "
+                         "with SYNTHETIC QoT tables (levels 1..6 at random): a timing, not a reference workload")
     args = ap.parse_args()
     import torch
     from conftest import load_phy_tables, load_topology
     from optical_rl_gym_amd import BatchedPhyRMSAEnv
-    topo = load_topology("us14_3-paths_6-modulations")
-    pairs, mod, gsnr = load_phy_tables("us14_k3")
+    topo = load_topology(args.topology)
+    if args.topology.startswith("us14_3"):
+        pairs, mod, gsnr = load_phy_tables("us14_k3")
+    else:
+        import numpy as np
+        rng = np.random.default_rng(5)
+        N = topo.num_nodes
+        pairs = np.array([(a + 1, b + 1) for a in range(N) for b in range(a + 1, N)], dtype=np.int32)
+        mod = rng.integers(1, 7, size=(len(pairs), 268, max(3, topo.k_paths))).astype(np.uint8)
+        gsnr = rng.uniform(5.0, 25.0, size=mod.shape)
     env = BatchedPhyRMSAEnv(topo, args.batch, modulation_level=mod, connections_detail=pairs, gsnr=gsnr, load=args.load,
                             mean_service_holding_time=25, episode_length=200, seed=10, grooming=args.grooming,
                             defrag_period=args.period if args.defrag else None, number_moves=args.moves if args.defrag else None,
@@ -49,7 +60,7 @@ def main():
     dt = time.perf_counter() - t0
     red, _ = env.reduce_counters()
     st = env.episode_stats()
-    print(json.dumps({"metric": f"env steps/s, PhyRMSA US14 {args.policy}", "value": args.batch * args.steps / dt,
+    print(json.dumps({"metric": f"env steps/s, PhyRMSA {args.topology} {args.policy}", "kernel": env.last_kernel(), "node_vectors": bool(env.node_vectors), "value": args.batch * args.steps / dt,
                       "grooming": args.grooming, "defrag": args.defrag, "defrag_metric": args.metric,
                       "queue_overflow": int(st["queue_overflow"].max()),
                       "batch": args.batch, "steps": args.steps, "load": args.load, "metrics_every_step": args.metrics,
