@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ORLG_ABI_VERSION 2
+#define ORLG_ABI_VERSION 3
 
 enum {
     ORLG_OK = 0,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"liborlg.so does not export {name}"
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert L.orlg_abi_version() == 2
+    assert L.orlg_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device(nsfnet):
