@@ -1275,19 +1275,40 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
 #pragma unroll
             for (int s = 0; s < RC; ++s)
                 if (lane + 64 * s < nc) cand_fill(v0[s], v1[s]);
+            // All pairs, but on ONE 64-bit key per candidate that decides nearly every pair: the integer gain and the age rounded
+            // to float32 (cut metric), the gain's bits (RSS metric).  A greater key precedes, a smaller one does not (rounding
+            // is monotone); only equal keys -- the channels of one service, ages closer than 2^-24 -- take the exact three-part
+            // comparison.  3 instead of 7 vector instructions per pair.
+            u64 kf[RC];
+#pragma unroll
+            for (int s = 0; s < RC; ++s) {
+                const double rd = __hiloint2double((int)v0[s].y, (int)v0[s].x), ra = __hiloint2double((int)v0[s].w, (int)v0[s].z);
+                kf[s] = rss ? (u64)__double_as_longlong(rd) : (((u64)(uint32_t)(int)rd << 32) | (u64)__float_as_uint((float)ra));
+                if (lane + 64 * s >= nc) kf[s] = 0ull;
+            }
 #pragma unroll
             for (int t = 0; t < RC; ++t) {
                 const int cnt = nc - 64 * t < 64 ? nc - 64 * t : 64;
                 for (int l = 0; l < cnt; ++l) {   // candidate (l, t) against every lane's own
-                    const double jd = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].y, l), __builtin_amdgcn_readlane((int)v0[t].x, l));
-                    const double ja = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].w, l), __builtin_amdgcn_readlane((int)v0[t].z, l));
-                    const uint32_t jx = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].x, l), jc = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].y, l);
-                    const u64 jo = ((u64)jx << 4) | (u64)(jc >> 25);   // order among equal (diff, age): running_services, then channel position
+                    const u64 jk = readlane64(kf[t], l);
+                    int ties = 0;
 #pragma unroll
                     for (int s = 0; s < RC; ++s) {
-                        const double rd = __hiloint2double((int)v0[s].y, (int)v0[s].x), ra = __hiloint2double((int)v0[s].w, (int)v0[s].z);
-                        const u64 ro = ((u64)v1[s].x << 4) | (u64)(v1[s].y >> 25);
-                        rank[s] += (jd > rd || (jd == rd && (ja > ra || (ja == ra && jo < ro)))) ? 1 : 0;
+                        if (64 * s >= nc) continue;   // (wave-uniform: no candidate in this slot of any lane)
+                        rank[s] += jk > kf[s] ? 1 : 0;
+                        ties += popc64(ballot(jk == kf[s]));
+                    }
+                    if (ties > 1) {   // (itself is one)
+                        const double jd = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].y, l), __builtin_amdgcn_readlane((int)v0[t].x, l));
+                        const double ja = __hiloint2double(__builtin_amdgcn_readlane((int)v0[t].w, l), __builtin_amdgcn_readlane((int)v0[t].z, l));
+                        const uint32_t jx = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].x, l), jc = (uint32_t)__builtin_amdgcn_readlane((int)v1[t].y, l);
+                        const u64 jo = ((u64)jx << 4) | (u64)(jc >> 25);   // order among equal (diff, age): running_services, then channel position
+#pragma unroll
+                        for (int s = 0; s < RC; ++s) {
+                            const double rd = __hiloint2double((int)v0[s].y, (int)v0[s].x), ra = __hiloint2double((int)v0[s].w, (int)v0[s].z);
+                            const u64 ro = ((u64)v1[s].x << 4) | (u64)(v1[s].y >> 25);
+                            if (jk == kf[s]) rank[s] += (jd > rd || (jd == rd && (ja > ra || (ja == ra && jo < ro)))) ? 1 : 0;
+                        }
                     }
                 }
             }
@@ -1301,33 +1322,52 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             wave_sync();
         }
-        // Round q's inputs -- the candidate's record (dword `lane` on lanes 0..7) and what the tables say about its path (the mask
-        // of the channels of its modulation level: lane w < W; its path's node weights: dword `lane`, lanes 0..7) -- are requested
-        // a round ahead (the record two), so that a round waits for no memory: it reads the path's free words and D from LDS,
-        // scores the free channels of that level, and touches the service record only when it moves.
+        // The rounds, eight candidates at a time.  A group's records sit on the lanes (lane 8 c + d: dword d of candidate c, one
+        // coalesced load, requested two groups ahead), and so does what the tables say about their paths (lane 8 c + w: the mask
+        // of the channels of candidate c's modulation level in word w; lane 8 c + d: dword d of its path's node weights --
+        // requested a group ahead): a round waits for no memory.  The free words of all eight paths come from ONE pass over
+        // (candidate, word) lanes, as the policy reads its k candidate paths; then the candidates take their turns: free words
+        // AND level mask off the lanes, D from LDS, the vote "does any channel beat -diff", the reduction to the best channel
+        // only when it passes.  A move (one round in fifteen) changes what the later candidates of the group would see: the
+        // next group starts right behind it.
         SEC(14);  // defragmentation: candidate rounds
+        constexpr int GR = 8;
         uint32_t rec_a = 0u, rec_b = 0u, tn_a = 0u;
         u64 tm_a = 0ull;
-        auto issue_tables = [&](uint32_t rv, u64 &tm, uint32_t &tn) {
-            const uint32_t x6 = (uint32_t)__builtin_amdgcn_readlane((int)rv, 6), ridp = (uint32_t)__builtin_amdgcn_readlane((int)rv, 7);
-            if (lane < W) tm = p.lvl_mask[((size_t)ridp * 32 + ((x6 >> 16) & 31u)) * W + lane];
-            if (gnv && !rss && lane < 8) tn = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * (x6 & 0xffffu))[lane];
+        const int gc = lane >> 3, gd = lane & 7;   // candidate of the group, dword / word
+        auto load_recs = [&](int q0) -> uint32_t {  // records q0 .. q0 + 7 of the sorted list
+            uint32_t v = 0u;
+            if (q0 + gc < nc) v = reinterpret_cast<const uint32_t *>(scand + q0)[lane];
+            return v;
         };
-        if (sorted && nc > 0) {
-            if (lane < 8) rec_a = reinterpret_cast<const uint32_t *>(scand)[lane];
-            if (nc > 1 && lane < 8) rec_b = reinterpret_cast<const uint32_t *>(scand + 1)[lane];
-            issue_tables(rec_a, tm_a, tn_a);
-        }
-        for (int round = 0; round < nc; ++round) {  // every round retires one candidate
-            uint32_t cv, tnq = 0u;
+        auto issue_tables = [&](uint32_t rv, int gsz, u64 &tm, uint32_t &tn) {
+            const uint32_t x6 = (uint32_t)__shfl((int)rv, (lane & ~7) + 6), ridp = (uint32_t)__shfl((int)rv, (lane & ~7) + 7);
+            tm = 0ull; tn = 0u;
+            if (gc < gsz) {
+                if (gd < W) tm = p.lvl_mask[((size_t)ridp * 32 + ((x6 >> 16) & 31u)) * W + gd];
+                if (gnv && !rss) tn = reinterpret_cast<const uint32_t *>(p.nvrec + 2 * (x6 & 0xffffu))[gd];
+            }
+        };
+        int q0 = 0;
+        bool fresh = true;   // the group's inputs have to be fetched now (the first group, the group behind a move)
+        while (q0 < nc) {
+            uint32_t rv, tnq = 0u;
             u64 tmq = 0ull;
+            int gsz;
             if (sorted) {
-                cv = rec_a; tmq = tm_a; tnq = tn_a;
+                gsz = nc - q0 < GR ? nc - q0 : GR;
+                if (fresh) {
+                    rec_a = load_recs(q0);
+                    rec_b = load_recs(q0 + GR);
+                    issue_tables(rec_a, gsz, tm_a, tn_a);
+                    fresh = false;
+                }
+                rv = rec_a; tmq = tm_a; tnq = tn_a;
                 rec_a = rec_b;
-                if (round + 2 < nc && lane < 8) rec_b = reinterpret_cast<const uint32_t *>(scand + round + 2)[lane];
-                if (round + 1 < nc) issue_tables(rec_a, tm_a, tn_a);
+                rec_b = load_recs(q0 + 2 * GR);
+                if (q0 + GR < nc) issue_tables(rec_a, nc - q0 - GR < GR ? nc - q0 - GR : GR, tm_a, tn_a);
             } else {
-                // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order)
+                // next candidate of sorted(key=(-diff, -age)) (stable: running_services order, then channel order): a group of one
                 double bd = -1.0, ba = 0.0;
                 u64 bo = ~0ull;
                 int bc = -1;
@@ -1345,66 +1385,81 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                 const double O = -wave_max_f64((bc >= 0 && bd == D && ba == A) ? -(double)bo : ninf);
                 const int wl = ctz64(ballot(bc >= 0 && bd == D && ba == A && (double)bo == O));
                 const int cb = __builtin_amdgcn_readlane(bc, wl);
-                cv = lane < 8 ? reinterpret_cast<const uint32_t *>(cand + cb)[lane] : 0u;
+                rv = lane < 8 ? reinterpret_cast<const uint32_t *>(cand + cb)[lane] : 0u;
                 wave_sync();
                 if (lane == 0) cand[cb].diff = -1.0;
-                issue_tables(cv, tmq, tnq);
+                gsz = 1;
+                issue_tables(rv, 1, tmq, tnq);
             }
-            const double diff = __hiloint2double(__builtin_amdgcn_readlane((int)cv, 1), __builtin_amdgcn_readlane((int)cv, 0));
-            const uint32_t x5 = (uint32_t)__builtin_amdgcn_readlane((int)cv, 5);
-            const int idx = (int)(x5 & 0xffffu), ch = (int)((x5 >> 16) & 0x1ffu);
-            const int gid = (int)((uint32_t)__builtin_amdgcn_readlane((int)cv, 6) & 0xffffu);
-            const OrlgPhySvc *r = grec + idx;
+            // free on the path and of the candidate's modulation level: only those channels can take it over -- all candidates of
+            // the group at once, lane = (candidate, word)
+            u64 acc_g;
             {
+                const int gid_l = (int)((uint32_t)__shfl((int)rv, (lane & ~7) + 6) & 0xffffu);
+                const bool on = gc < gsz && gd < W;
+                acc_g = path_word<W>(occ, tb.recs, gid_l, gd < W ? gd : 0, on) & (on ? tmq : 0ull);
+            }
+            bool moved_in_group = false;
+            int c = 0;
+            for (; c < gsz; ++c) {
+                const int l8 = 8 * c;
+                const double diff = __hiloint2double(__builtin_amdgcn_readlane((int)rv, l8 + 1), __builtin_amdgcn_readlane((int)rv, l8));
+                const uint32_t x5 = (uint32_t)__builtin_amdgcn_readlane((int)rv, l8 + 5);
+                const int idx = (int)(x5 & 0xffffu), ch = (int)((x5 >> 16) & 0x1ffu);
+                const int gid = (int)((uint32_t)__builtin_amdgcn_readlane((int)rv, l8 + 6) & 0xffffu);
+                const OrlgPhySvc *r = grec + idx;
                 const OrlgPathRec *rec = tb.recs + gid;
-                // free on the path and of the candidate's modulation level: only those channels can take it over
-                u64 acc = path_word<W>(occ, tb.recs, gid, lane < W ? lane : 0, lane < W);
-                acc &= lane < W ? tmq : 0ull;
+                u64 xw[W];
+                u64 any = 0ull;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { xw[w] = readlane64(acc_g, l8 + w); any |= xw[w]; }
                 int l0 = -1, c0 = -1;
                 double m0 = 0.0;
-                if (gnv && !rss) {
-                    // cut metric of the lane's channels from D (LDS) and the path's node weights: an integer; the best channel =
-                    // greatest metric, then lowest channel number, as ONE key
-                    // Four rounds in five find a free channel of that level, one in fifteen moves: the vote "some channel's
-                    // metric beats -diff" comes first, the reduction to the best channel only when it passes.
-                    if (ballot(acc != 0ull) != 0ull) {
+                if (any != 0ull) {
+                    if (gnv && !rss) {
+                        // cut metric of the lane's channels from D (LDS) and the path's node weights: an integer; the best channel
+                        // = greatest metric, then lowest channel number, as ONE key.  Four rounds in five find a free channel of
+                        // that level, one in fifteen moves: the vote comes first, the reduction only when it passes.
                         uint4 qa, qb;
-                        qa.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 0); qa.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 1);
-                        qa.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 2); qa.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 3);
-                        qb.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 4); qb.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 5);
-                        qb.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 6); qb.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, 7);
+                        qa.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 0); qa.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 1);
+                        qa.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 2); qa.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 3);
+                        qb.x = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 4); qb.y = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 5);
+                        qb.z = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 6); qb.w = (uint32_t)__builtin_amdgcn_readlane((int)tnq, l8 + 7);
                         const NvRec nr = nv_unpack(qa, qb);
-                        nv_fence();
                         int key = -1;
                         // -metric < diff with an integer metric and an integer-valued diff: metric + 1024 > 1024 - diff
                         const int kthr = ((1024 - (int)diff) << 9) | 511;
 #pragma unroll
                         for (int w = 0; w < W; ++w) {
-                            const u64 x = readlane64(acc, w);
+                            const u64 x = xw[w];
                             if (x == 0ull) continue;   // (wave-uniform: no free channel of that level in this word)
                             const int cc = 64 * w + lane;
                             const bool fr = ((x >> lane) & 1ull) && cc < p.C;
-                            int s = nv_dot(nr.c, nv_get(gnv, cc, p.C)) - nr.cq;
-                            if (nr.nchord) s -= nv_chords(occ, nr, cc, W);
-                            const int kk = ((nr.wsum - 2 * s + 1024) << 9) | (511 - cc);   // |metric| <= sum of the weights < 1024
+                            int sdot = nv_dot(nr.c, nv_get(gnv, cc, p.C)) - nr.cq;
+                            if (nr.nchord) sdot -= nv_chords(occ, nr, cc, W);
+                            const int kk = ((nr.wsum - 2 * sdot + 1024) << 9) | (511 - cc);   // |metric| <= sum of the weights < 1024
                             if (fr && kk > key) key = kk;
                         }
                         if (ballot(key > kthr) != 0ull) {
                             key = wave_max_i32(key);
                             l0 = 0; c0 = 511 - (key & 511); m0 = (double)((key >> 9) - 1024);
                         }
-                    }
-                } else {
-                    int lv[W];
-                    double mtr[W];
-                    uint32_t cols[W];
-                    uint4 dv0[W];
+                    } else {
+                        int lv[W];
+                        double mtr[W];
+                        uint32_t cols[W];
+                        uint4 dv0[W];
 #pragma unroll
-                    for (int w = 0; w < W; ++w) dv0[w] = make_uint4(0u, 0u, 0u, 0u);
-                    const uint8_t *mrow = p.mod_t + (size_t)__builtin_amdgcn_readlane((int)cv, 7) * p.cpad;   // (levels: not looked at, flat)
-                    phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
-                    phy_row_metrics<W>(occ, tb, p, acc, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv0);
-                    phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
+                        for (int w = 0; w < W; ++w) dv0[w] = make_uint4(0u, 0u, 0u, 0u);
+                        u64 acc1 = 0ull;   // the candidate's free words as phy_row_metrics takes them: word w on lane w
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                            if (lane == w) acc1 = xw[w];
+                        const uint8_t *mrow = p.mod_t + (size_t)__builtin_amdgcn_readlane((int)rv, l8 + 7) * p.cpad;   // (levels: not looked at, flat)
+                        phy_columns<W>(occ, tb, p, lane, rss ? 1 : 0, cols, r0w);
+                        phy_row_metrics<W>(occ, tb, p, acc1, 0, gid, mrow, lane, rss ? 1 : 0, true, lv, mtr, cols, r0w, dv0);
+                        phy_row_best<W>(lv, mtr, lane, l0, m0, c0);  // sorted(key=(-metric, channel))[0]
+                    }
                 }
                 if (l0 >= 0 && -1.0 * m0 < diff) {
                     // _move (:662-697): the service's channel list is read now -- the moved entry goes to its end
@@ -1413,7 +1468,7 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                     const int mych = lane < nch ? (int)r->ch[lane] : 0xffff;
                     const u64 jm = ballot(lane < nch && (mych & 0x1ff) == ch && !(mych & (1 << 14)));
                     if (jm) {
-                        const int j = ctz64(jm);
+                        const int jpos = ctz64(jm);
                         mc_before(occ, mc, c0, lane);
                         mc_before(occ, mc, ch, lane);
                         if (lane < rec->hops) {
@@ -1430,8 +1485,8 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                         }
                         const int nxtc = __shfl_down(mych, 1);
                         int nv2 = mych;
-                        if (lane >= j && lane + 1 < nch) nv2 = nxtc;
-                        if (lane == nch - 1) nv2 = c0 | (readlane64((u64)(uint32_t)mych, j) & 0xfe00u);
+                        if (lane >= jpos && lane + 1 < nch) nv2 = nxtc;
+                        if (lane == nch - 1) nv2 = c0 | (readlane64((u64)(uint32_t)mych, jpos) & 0xfe00u);
                         if (lane < nch) grec[idx].ch[lane] = (uint16_t)nv2;
                         {
                             const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane(nv2, 0), h1 = (uint32_t)__builtin_amdgcn_readlane(nv2, 1);
@@ -1443,11 +1498,15 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
                         }
                         next_seq += 1;
                         cmoves += 1;
+                        moved_in_group = true;
                         wave_sync();
                     }
                 }
+                if (cmoves + gmoves > p.number_moves || moved_in_group) { c += 1; break; }
             }
             if (cmoves + gmoves > p.number_moves) break;
+            q0 += c;                 // (the candidates behind a move see the new occupancy: their group is read again)
+            if (moved_in_group) fresh = true;
         }
         cycles = cmoves != 0 ? 1 : 0;
     }
