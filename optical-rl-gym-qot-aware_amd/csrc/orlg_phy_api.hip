@@ -560,6 +560,11 @@ int orlg_phy_create(const orlg_topology *t, const orlg_phy_config *c, int32_t ba
         p.gn_A = d_A; p.gn_R = d_R; p.gn_link = d_L;
     }
     if (p.use_masks) TRY(alloc(reinterpret_cast<void **>(&p.cterm), (size_t)batch * p.cpad * sizeof(double)));   // (scratch, see OrlgPhyParams)
+    if (p.use_masks) {   // the deferred channel-order sums (MetricCache): scratch too
+        TRY(alloc(reinterpret_cast<void **>(&p.rlog_t0), (size_t)batch * p.cpad * sizeof(double)));
+        TRY(alloc(reinterpret_cast<void **>(&p.rlog_val), (size_t)batch * ORLG_RLOG_CAP * sizeof(double)));
+        TRY(alloc(reinterpret_cast<void **>(&p.rlog_key), (size_t)batch * ORLG_RLOG_CAP * sizeof(uint32_t)));
+    }
     if (p.defrag_period > 0) {
         // defragmentation work list: one entry per channel in use that a service fills (candidates of the physical pass)
         p.cand_cap = c->defrag_capacity > 0 ? c->defrag_capacity : 2 * Q;

@@ -120,6 +120,10 @@ struct OrlgPhyParams {
     const double *gn_A;         // [C][cpad] asinh(k (f_c - f_ch + bw/2)) - asinh(k (f_c - f_ch - bw/2)), 0 on the diagonal
     const double *gn_R;         // [C][cpad] bw / |f_c - f_ch|, 0 on the diagonal
     const double *gn_link;      // [E][4] l_eff, l_eff / span length, exp(2 att len) - 1, -; then [4E] = the self-channel asinh term
+    // the channel-order sums of rss_total_metric, deferred (mc_flush): per env the terms at the start of a block of steps [cpad]
+    // and the block's log of rewritten terms (value; channel | stamp << 16) [ORLG_RLOG_CAP each]
+    double *rlog_t0, *rlog_val;
+    uint32_t *rlog_key;
     double *cterm;          // [B][cpad] scratch: per-channel term of calculate_total_r_spatial while a launch keeps the per-step
                             // totals incrementally (not part of the state: rebuilt at the start of every launch that needs it)
     const uint8_t *mod_t;   // [num_rows*K][cpad] modulation level per channel
@@ -731,8 +735,15 @@ DEV double wave_min_key(uint32_t key, bool has) {
 // subtracts the column's runs before it changes the occupancy and adds them back afterwards (mc_before / mc_after, wave
 // uniform: the column = one ballot over link lanes), and rewrites the column's term; the per-step output is then the integer
 // total and the ordered sum of the cached terms instead of a rebuild of all 268 columns.
+#define ORLG_RLOG_CAP 384
 struct MetricCache {
     bool on, want_rss;
+    // the channel-order float64 sum of the RSS terms is a chain of C dependent additions per step -- a fifth of a step with the
+    // metrics written.  A launch of many steps defers it: every rewritten term is logged (value, channel, the number
+    // of output points passed in the block), and once per block of up to 64 steps the sums of ALL its steps are formed at once,
+    // lane = step, every lane the same chain over ITS step's terms (mc_flush): C additions per block instead of per step.
+    bool defer, log_overflow;
+    int nlog, stamp, t0, env;   // (the log's arrays are addressed from the kernel arguments where they are used: OrlgPhyParams::rlog_*)
     int total_runs;
     double *cterm;          // HBM [cpad]
     double __attribute__((address_space(3))) *lterm;   // the same terms in LDS (mc_after<true>)
@@ -760,7 +771,80 @@ DEV void mc_after(const u64 *occ, MetricCache &mc, int ch, int lane) {
         if (lane == 0) {
             if (LT) mc.lterm[ch] = t; else mc.cterm[ch] = t;
         }
+        if (mc.defer) {
+            if (mc.nlog < ORLG_RLOG_CAP) {
+                if (lane == 0) {
+                    const OrlgPhyParams __attribute__((address_space(4))) *kq =
+                        (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+                    const size_t at = (size_t)mc.env * ORLG_RLOG_CAP + mc.nlog;
+                    kq->rlog_val[at] = t; kq->rlog_key[at] = (uint32_t)ch | ((uint32_t)mc.stamp << 16);
+                }
+                mc.nlog += 1;
+            } else {
+                mc.log_overflow = true;   // (reported: more than 160 terms rewritten in one step)
+            }
+        }
     }
+}
+// The deferred sums of a block: lane t = the block's step t.  Channel by channel in the reference's order (calculate_total_r_spatial
+// adds the terms one by one, phy_rmsa_env.py:1117): the term as it was at the block's start, unless the log holds a rewrite
+// the step has seen (stamp <= t; the last such).  Channels without a logged rewrite (a bit mask in LDS tells) cost one addition.
+template <int W>
+DEV void mc_flush(MetricCache &mc, const double *terms_now /* LDS [W*64] */, u64 *ormask /* LDS [W] */, int C, int cpad, int lane,
+                  uint64_t out_rss, size_t B) {
+    constexpr int SL = ORLG_RLOG_CAP / 64;
+    const OrlgPhyParams __attribute__((address_space(4))) *kq =
+        (const OrlgPhyParams __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t *lkey = kq->rlog_key + (size_t)mc.env * ORLG_RLOG_CAP;
+    const double *lval = kq->rlog_val + (size_t)mc.env * ORLG_RLOG_CAP;
+    double *lt0 = kq->rlog_t0 + (size_t)mc.env * cpad;
+    const int nb = mc.stamp, nlog = mc.nlog;
+    uint32_t key[SL];
+    double val[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        const int i = lane + 64 * q;
+        key[q] = 0xffffffffu; val[q] = 0.0;
+        if (i < nlog) { key[q] = lkey[i]; val[q] = lval[i]; }
+    }
+    if (lane < W) ormask[lane] = 0ull;
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < SL; ++q)
+        if (lane + 64 * q < nlog) {
+            const int ch = (int)(key[q] & 0xffffu);
+            atomicOr(reinterpret_cast<unsigned long long *>(ormask + (ch >> 6)), 1ull << (ch & 63));
+        }
+    wave_sync();
+    double S = 0.0;
+    for (int w = 0; w < W; ++w) {
+        const double t0v = lt0[64 * w + lane];   // (one round trip per word and block: a block is 64 steps)
+        const u64 m = readlane64(ormask[w], 0);
+        const int cmax = C - 64 * w < 64 ? C - 64 * w : 64;
+        for (int c = 0; c < cmax; ++c) {
+            double v = readlane_d(t0v, c);
+            if ((m >> c) & 1ull) {
+                const uint32_t chk = (uint32_t)(64 * w + c);
+#pragma unroll
+                for (int q = 0; q < SL; ++q) {
+                    if (64 * q >= nlog) continue;
+                    for (u64 mm = ballot((key[q] & 0xffffu) == chk); mm; mm &= mm - 1) {   // in log order: ascending lane, then slot
+                        const int l = ctz64(mm);
+                        const int st = (int)((uint32_t)__builtin_amdgcn_readlane((int)key[q], l) >> 16);
+                        const double vv = readlane_d(val[q], l);
+                        if (lane >= st) v = vv;
+                    }
+                }
+            }
+            S += v;
+        }
+    }
+    if (lane < nb) ORLG_GPTR(double, out_rss)[(size_t)(mc.t0 + lane) * B + mc.env] = S / (double)C;
+    // the next block starts from the terms as they are now (what the log held after the last output point is in them)
+#pragma unroll
+    for (int w = 0; w < W; ++w) lt0[64 * w + lane] = terms_now[64 * w + lane];
+    mc.t0 += nb;
+    mc.nlog = 0; mc.stamp = 0;
 }
 
 // The periodic defragmentation of PhyRMSAEnv.step (phy_rmsa_env.py:355-417), run when services_processed is a multiple of
@@ -1750,12 +1834,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
     // the terms go to the HBM array for its duration -- once in defrag_period steps instead of a round trip every step)
     constexpr bool LT = !RSSP;
     mc.sqrt_tab = tb.sqrt_tab; mc.E = E; mc.W = W;
+    // (launches of few steps -- the gym views -- sum every step: a block of one step would cost more than its chain)
+    mc.defer = LT && mc.on && mc.want_rss && p.rlog_t0 != nullptr && p.n_steps >= 16;
+    mc.log_overflow = false; mc.nlog = 0; mc.stamp = 0; mc.t0 = 0; mc.env = env;
     if (mc.on) {
         double c0_unused, r0_unused;
         phy_column_metrics<W>(occ, tb.sqrt_tab, E, C, lane, scratch_d, true, mc.want_rss, true, c0_unused, r0_unused, mc.total_runs);
         if (mc.want_rss && !LT) {
             for (int ch = lane; ch < C; ch += 64) mc.cterm[ch] = scratch_d[ch];
             wave_sync();
+        }
+        if (mc.defer) {
+            double *lt0 = p.rlog_t0 + (size_t)env * p.cpad;
+#pragma unroll
+            for (int w = 0; w < W; ++w) lt0[64 * w + lane] = scratch_d[64 * w + lane];
         }
     }
 
@@ -2209,7 +2301,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 const bool want_c = om & (1 << ORLG_PHY_OUT_CUTS), want_r = om & (1 << ORLG_PHY_OUT_RSS);
                 if (mc.on) {
                     cuts = (double)mc.total_runs / (double)C;
-                    if (want_r) {
+                    if (want_r && mc.defer) {
+                        mc.stamp += 1;   // this step's output point: its sum is formed with the block's (mc_flush, below)
+                    } else if (want_r) {
                         // the terms lane 0 rewrote in this step are complete (same wave: in order).  Through LDS, then the
                         // reference's channel-order float64 sum: 8 terms per LDS round trip (one trip per term made this sum
                         // half of the step), the zero terms past C leave the sum as it is
@@ -2249,7 +2343,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                     }
                     if (om & (1 << ORLG_PHY_OUT_GN)) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_GN])[o] = gn_last;
                     if (want_c) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_CUTS])[o] = cuts;
-                    if (want_r) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
+                    if (want_r && !mc.defer) ORLG_GPTR(double, tb.outs[ORLG_PHY_OUT_RSS])[o] = rss;
+                }
+                // a block of deferred sums is due: 64 steps, or a log that the next step's rewrites might overrun
+                if (mc.defer && (mc.stamp == 64 || mc.nlog > ORLG_RLOG_CAP - 160)) {
+                    nv_fence();
+                    mc_flush<W>(mc, scratch_d, reinterpret_cast<u64 *>(scratch), C, p.cpad, lane, tb.outs[ORLG_PHY_OUT_RSS], (size_t)p.B);
+                    wave_sync();
                 }
             }
             new_service = 0;
@@ -2497,6 +2597,12 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
     }
 
+    if (mc.defer) {   // the last block's sums
+        wave_sync();
+        if (mc.stamp > 0) mc_flush<W>(mc, scratch_d, reinterpret_cast<u64 *>(scratch), C, p.cpad, lane, tb.outs[ORLG_PHY_OUT_RSS], (size_t)p.B);
+        if (mc.log_overflow && lane == 0) ws->q_overflow |= 16;
+        wave_sync();
+    }
     SEC(13);  // state store
     // ------------------------------------------------------------------ LDS -> HBM
     wave_sync();
