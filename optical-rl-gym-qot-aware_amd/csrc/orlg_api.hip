@@ -49,6 +49,8 @@ struct orlg_env {
     int group_resident[ORLG_GROUP_WAVES + 1];   // resident workgroups by waves per workgroup (0 = not asked yet)
     int group_wpb_hq, group_wave_bytes_hq;      // the same for launches that leave the release queue in HBM (orlg_rmsa_group_kernel<.., true>)
     int group_resident_hq[ORLG_GROUP_WAVES + 1];
+    int group_resident_df[ORLG_GROUP_WAVES + 1];   // ... of the instantiation with the link statistics deferred
+    uint4 *llog;             // its log of link updates [B][E][64] (allocated with the first such launch)
     size_t group_lds_bytes;
     int num_cu;
     uint32_t ticket_base;
@@ -280,9 +282,17 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     const bool hq = p.n_steps <= ORLG_DIRECT_STEPS && e->group_wpb_hq > e->group_wpb;
     const int wave_bytes = hq ? e->group_wave_bytes_hq : p.g_wave_bytes;
     const int wpb_max = hq ? e->group_wpb_hq : e->group_wpb;
-    int *resident = hq ? e->group_resident_hq : e->group_resident;
-    rmsa_kernel_t k = pick_group(e->W, p.stats_level + (hq ? 4 : 0));
+    // long launches with full statistics whose outputs do not read the link statistics step by step: the instantiation that
+    // logs the links' updates and works them off one link per lane (group_link_replay)
+    const bool df = !hq && p.stats_level >= 2 && p.n_steps >= 16 && !getenv("ORLG_NO_DEFER") &&
+                    !(p.out_mask & ((1 << ORLG_OUT_AVG_LINK_COMPACT) | (1 << ORLG_OUT_AVG_LINK_UTIL)));
+    int *resident = hq ? e->group_resident_hq : df ? e->group_resident_df : e->group_resident;
+    rmsa_kernel_t k = pick_group(e->W, p.stats_level + (hq ? 4 : df ? 8 : 0));
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
+    if (df && !e->llog) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->llog), (size_t)p.B * p.E * 64 * sizeof(uint4)));
+        e->bufs.push_back(e->llog);
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb_max * wave_bytes)));
     const int n_quads = (p.B + 3) / 4;
@@ -308,6 +318,7 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     int nblocks = (n_quads + wpb - 1) / wpb;
     if (nblocks > resident[wpb]) nblocks = resident[wpb];
     OrlgParams q = p;
+    q.llog = df ? e->llog : nullptr;
     q.g_wave_bytes = wave_bytes;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
@@ -316,7 +327,7 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
     snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d%s> grid=%d block=%d lds=%zu", e->W, p.stats_level,
-             hq ? ",true" : "", nblocks, ORLG_WAVE * wpb, lds_bytes);
+             hq ? ",true" : df ? ",false,true" : "", nblocks, ORLG_WAVE * wpb, lds_bytes);
     return ORLG_OK;
 }
 
@@ -630,7 +641,8 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb; cand--)
             if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * p.g_wave_bytes <= 160 * 1024) e->group_wpb = cand;
         e->group_lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)e->group_wpb * p.g_wave_bytes;
-        for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = e->group_resident_hq[w] = 0;
+        for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = e->group_resident_hq[w] = e->group_resident_df[w] = 0;
+        e->llog = nullptr;
         e->group_wave_bytes_hq = p.g_qtime;   // the region ends where the ring's slices would begin (they are the last arrays)
         e->group_wpb_hq = 0;
         for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb_hq; cand--)

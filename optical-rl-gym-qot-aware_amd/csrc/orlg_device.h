@@ -85,6 +85,7 @@ struct OrlgParams {
     int32_t *lint;            // [B][lint_stride] per-link span | gaps << 16 (the cache behind _get_network_compactness)
     int32_t lint_stride;
     int32_t obs_f32;          // orlg_deeprmsa_obs_kernel writes float32 (o_obs then points to floats)
+    uint4 *llog;              // [B][E][ORLG_LLOG_CAP] logged link-statistics updates (orlg_rmsa_group_kernel<.., DEFER>), scratch
     int32_t br_width, pad_br;  // bit_rate_selection="continuous": number of bit rates lower .. higher (the table bit_rates holds them), 0 = discrete
     double *ring_iat, *ring_ht;   // [B][64] pre-generated inter-arrival / holding times (in RNG stream order)
     uint32_t *ring_req;           // [B][64] src | dst << 8 | bit-rate index << 16

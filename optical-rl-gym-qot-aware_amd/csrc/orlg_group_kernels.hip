@@ -72,10 +72,19 @@ ORLG_SEG_REDUCE(seg_max, ORLG_OP_MAX)
 
 // link statistics of up to ORLG_MAX_HOPS links per row: link_stats_update (orlg_kernels.hip) with 16 / W links per row and
 // pass, one word per lane; nlinks = 0 for a row that does not take part.  links: the row's link indices (bytes, LDS).
-template <int W, bool LINKF, bool GRAPH>
+// DEFER: the float64 part of _update_link_stats is not done here.  It is a recurrence PER LINK -- the time-weighted means of
+// utilization, external fragmentation and compactness since the link's last update -- of ~100 instructions that every lane of
+// the row executes for the one to three links a pass holds: 29 % of this kernel's instructions.  The deferred form logs what
+// the recurrence consumes (the integers behind cur0..2 and the time: 16 bytes) per (environment, link) in HBM, counts the
+// entries in the upper bits of the link's span cache, and group_link_replay works the logs off with ONE LINK PER LANE, sixteen
+// links of an environment at a time, every lane through its own link's events in their order -- the same operations on the
+// same values, so the same bits.
+#define ORLG_LLOG_CAP 64      // logged updates per (environment, link) between two replays (6-bit count)
+#define ORLG_LLOG_FLUSH 40    // a link that reaches this many asks for a replay at the end of the step
+template <int W, bool LINKF, bool GRAPH, bool DEFER = false>
 DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint8_t *links,
                           int nlinks, double now, int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr,
-                          double &g_thr, double &g_comp, double &g_lu) {
+                          double &g_thr, double &g_comp, double &g_lu, uint4 *llog = nullptr, bool *need_replay = nullptr) {
     static_assert(W <= 8, "at least two links per row");
     constexpr int NS = ORLG_GL / W;  // links per row and pass
     const int gl = lane & 15;
@@ -143,13 +152,27 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         if (link_lane) {
             int nspan = U > 1 ? lmax - lmin : 0, ngaps = U > 1 ? U - 1 : 0;
             int old = lint[link];
-            lint[link] = nspan | (ngaps << 16);
+            int cnt = 0;
+            if (LINKF && DEFER) {
+                // the update's inputs, for group_link_replay: free slots, max_empty, span, used runs | the time
+                cnt = (int)((uint32_t)old >> 26);
+                const int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? (int)ml : 0;
+                if (cnt < ORLG_LLOG_CAP - 1) {
+                    llog[__mul24(link, ORLG_LLOG_CAP) + cnt] =
+                        make_uint4((uint32_t)freec | ((uint32_t)max_empty << 10) | ((uint32_t)(lmax - lmin) << 20), (uint32_t)U,
+                                   (uint32_t)__double2loint(now), (uint32_t)__double2hiint(now));
+                    cnt += 1;
+                }
+                if (cnt >= ORLG_LLOG_FLUSH) *need_replay = true;
+                old &= 0x03ffffff;
+            }
+            lint[link] = nspan | (ngaps << 16) | (cnt << 26);
             dspan = nspan - (old & 0xffff);
             dgaps = ngaps - (old >> 16);
         }
         sum_span += row_add_i32(dspan);
         sum_gaps += row_add_i32(dgaps);
-        if (LINKF && link_lane && now > 0) {
+        if (LINKF && !DEFER && link_lane && now > 0) {
             double *l_util = lst, *l_ef = lst + E, *l_c = lst + 2 * E, *l_lu = lst + 3 * E;
             const double last_update = l_lu[link];
             const double last0 = l_util[link], last1 = l_ef[link], last2 = l_c[link];
@@ -165,7 +188,7 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
             l_ef[link] = div_by((last1 * last_update) + (cur1 * time_diff), now, ynow);
             l_c[link] = div_by((last2 * last_update) + (cur2 * time_diff), now, ynow);
         }
-        if (LINKF && link_lane) lst[3 * E + link] = now;
+        if (LINKF && !DEFER && link_lane) lst[3 * E + link] = now;
         wave_sync();
     }
     if (GRAPH && nlinks > 0) {
@@ -178,6 +201,56 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
         }
         g_lu = now;
     }
+}
+
+// The logged link updates of the wave's four environments, worked off: lane gl of a row = link gl (+ 16, + 32, ...) of the row's
+// environment; every lane runs through its link's entries in their order with the link's four statistics in registers -- the
+// float64 operations of _update_link_stats (rmsa_env.py:562-641) as group_link_stats does them, one update after the other.
+DEV void group_link_replay(const int lane, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint4 *llog) {
+    const int gl = lane & 15;
+    // the entries other lanes of this wave logged: the stores only have to be complete (same CU)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int l0 = 0; l0 < E; l0 += ORLG_GL) {
+        const int link = l0 + gl;
+        const bool on = link < E;
+        const int li = on ? lint[link] : 0;
+        const int n = (int)((uint32_t)li >> 26);
+        if (ballot(n > 0) == 0ull) continue;
+        double s_util = 0.0, s_ef = 0.0, s_c = 0.0, s_lu = 0.0;
+        if (on) { s_util = lst[link]; s_ef = lst[E + link]; s_c = lst[2 * E + link]; s_lu = lst[3 * E + link]; }
+        const uint4 *row = llog + __mul24(on ? link : 0, ORLG_LLOG_CAP);
+        const int nmax = wave_max_i32(n);
+        uint4 e_nx = make_uint4(0u, 0u, 0u, 0u);
+        if (n > 0) e_nx = row[0];
+        for (int k = 0; k < nmax; ++k) {
+            const uint4 ev = e_nx;
+            if (k + 1 < n) e_nx = row[k + 1];   // (the next entry is requested before this one is worked on)
+            if (k < n) {
+                const int freec = (int)(ev.x & 0x3ffu), max_empty = (int)((ev.x >> 10) & 0x3ffu), span = (int)(ev.x >> 20), U = (int)ev.y;
+                const double now = __hiloint2double((int)ev.w, (int)ev.z);
+                if (now > 0) {
+                    const double ynow = recip_refine(now);
+                    const double cur0 = tb.div_s[S - freec];  // (S - free) / S
+                    double cur1 = 0.0, cur2 = 0.0;
+                    if (freec > 0) {
+                        cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
+                        cur2 = U > 1 ? ORLG_FDIV((double)span, (double)(S - freec)) * tb.inv_k[U] : 1.0;
+                    }
+                    const double time_diff = now - s_lu;
+                    s_util = div_by((s_util * s_lu) + (cur0 * time_diff), now, ynow);
+                    s_ef = div_by((s_ef * s_lu) + (cur1 * time_diff), now, ynow);
+                    s_c = div_by((s_c * s_lu) + (cur2 * time_diff), now, ynow);
+                }
+                s_lu = now;
+            }
+        }
+        if (on && n > 0) {
+            lst[link] = s_util; lst[E + link] = s_ef; lst[2 * E + link] = s_c; lst[3 * E + link] = s_lu;
+            lint[link] = li & 0x03ffffff;
+        }
+    }
+    wave_sync();
 }
 
 // set (release) or clear (provision) the window [s, s+n) on every link of a row's path; hops = 0: the row does not take part
@@ -236,8 +309,9 @@ DEV void row_copy8(u64 *dst, const u64 *src, int n, int gl) {
 // half of an environment's footprint there (its capacity, not its live part, sizes the region), and a one-step launch is
 // bound by how many waves a CU keeps resident, not by the queue's latency.  The ring logic is the same code on
 // global pointers; OrlgParams::g_wave_bytes of such a launch ends where the ring's LDS slices would begin.
-template <int W, int STATS, bool HBMQ = false>
+template <int W, int STATS, bool HBMQ = false, bool DEFER = false>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3) / 4) void orlg_rmsa_group_kernel(const OrlgParams p) {
+    static_assert(!DEFER || (STATS >= 2 && !HBMQ), "the deferred link statistics belong to long launches with full statistics");
     extern __shared__ __align__(16) unsigned char smem[];
     stage_tables(smem, p);
     const int lane = threadIdx.x & 63;
@@ -315,6 +389,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
             if (NET) for (int i = gl; i < p.lint_stride; i += ORLG_GL) lint[i] = (reinterpret_cast<int32_t *>(wbase + p.g_lint) + gs_ * p.lint_stride)[i];
         }
     }
+    // the link-update log of this row's environment (DEFER)
+    uint4 *llog = DEFER ? p.llog + (size_t)env * E * ORLG_LLOG_CAP : nullptr;
+    bool need_replay = false;
     const OrlgEnvScalars *gs = p.scal + env;
     double current_time = gs->current_time, req_arrival = gs->req_arrival, req_holding = gs->req_holding;
     double g_thr = gs->g_throughput, g_comp = gs->g_compactness, g_lu = gs->g_last_update;
@@ -490,8 +567,8 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         }
         SEC(4);  // statistics at provision
         if (NET)
-            group_link_stats<W, FULL, true>(lane, occ, lst, lint, tb, S, E, rec->link, accepted ? hops : 0, current_time, sum_span,
-                                            sum_gaps, comp_cur, sum_sh, (double)sum_bitrate_running, g_thr, g_comp, g_lu);
+            group_link_stats<W, FULL, true, DEFER>(lane, occ, lst, lint, tb, S, E, rec->link, accepted ? hops : 0, current_time, sum_span,
+                                                   sum_gaps, comp_cur, sum_sh, (double)sum_bitrate_running, g_thr, g_comp, g_lu, llog, &need_replay);
         SEC(5);  // queue insert
         {
             // ---- _add_release (optical_network_env.py:178-189): the entries that are released later move up one slot (from the
@@ -652,12 +729,20 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                 if (rel_now) next_rel = q_n > 0 ? qtime[q_head] : INF;   // the next entry
                 SEC(11);  // statistics at release
                 if (NET)
-                    group_link_stats<W, FULL, false>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
-                                                     sum_span, sum_gaps, comp_cur, sum_sh, 0.0, g_thr, g_comp, g_lu);
+                    group_link_stats<W, FULL, false, DEFER>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
+                                                            sum_span, sum_gaps, comp_cur, sum_sh, 0.0, g_thr, g_comp, g_lu, llog, &need_replay);
+                if (DEFER && ballot(need_replay) != 0ull) {   // (a link's log never grows past ORLG_LLOG_FLUSH + 1 entries)
+                    group_link_replay(lane, lst, lint, tb, S, E, llog);
+                    need_replay = false;
+                }
             }
             if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
         }
 
+        if (DEFER && ballot(need_replay) != 0ull) {   // a link's log is filling up: every row works its logs off
+            group_link_replay(lane, lst, lint, tb, S, E, llog);
+            need_replay = false;
+        }
         // ============================================================== done / episode reset
         SEC(12);
         {
@@ -682,6 +767,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         }
     }
 
+    if (DEFER) group_link_replay(lane, lst, lint, tb, S, E, llog);   // (the state that leaves carries no pending updates)
     // ------------------------------------------------------------------ LDS -> HBM
     SEC(13);  // state store
     wave_sync();

@@ -19,6 +19,7 @@ orlg_rmsa_kernel_t ORLG_CAT(orlg_group_kernel_W, ORLG_INST_W)(int stats) {
         case 4: return orlg_rmsa_group_kernel<W, 0, true>;
         case 5: return orlg_rmsa_group_kernel<W, 1, true>;
         case 6: return orlg_rmsa_group_kernel<W, 2, true>;
+        case 10: return orlg_rmsa_group_kernel<W, 2, false, true>;   // + 8: full statistics with the link updates deferred (long launches)
         default: return nullptr;
     }
 }

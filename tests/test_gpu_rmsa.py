@@ -342,7 +342,7 @@ def test_group_kernel_short_launches_keep_the_queue_in_hbm(nsfnet):
     while left:
         n = min(sizes[i % len(sizes)], left)
         parts.append(env.run("sap_ff", n, outputs=outs, auto_reset=True))
-        assert ",true>" in env.last_kernel(), env.last_kernel()
+        assert "<5,2,true>" in env.last_kernel(), env.last_kernel()
         left -= n
         i += 1
     for k in outs:
@@ -372,7 +372,7 @@ def test_group_kernel_ring_head_laps_the_queue(nsfnet):
     for n in (1000, 1000, 333, 1000):
         ta = a.run("sap_ff", n, outputs=outs, auto_reset=True)
         tb = b.run("sap_ff", n, outputs=outs, auto_reset=True)
-        assert "group_kernel" in b.last_kernel() and ",true>" not in b.last_kernel(), b.last_kernel()   # the ring in LDS
+        assert "group_kernel<5,2,false,true>" in b.last_kernel() or (n < 16 and "group_kernel<5,2>" in b.last_kernel()), b.last_kernel()   # the ring in LDS
         for k in outs:
             assert np.array_equal(ta[k], tb[k]), (n, k)
         assert np.array_equal(a.save_state(), b.save_state()), n
@@ -463,3 +463,42 @@ def test_reseed_between_launches_vs_oracle(nsfnet, device_log_in_oracle, step_ke
         assert np.array_equal(env.available_slots()[i], o.available_slots()), i
         o.close()
     env.close()
+
+
+def test_group_kernel_deferred_link_statistics(nsfnet, device_log_in_oracle):
+    """Long launches with full statistics run the group kernel's instantiation that LOGS the links' float64 updates and works
+    them off one link per lane (group_link_replay): the same operations on the same values.  Against the instantiation that
+    does them in place (ORLG_NO_DEFER, and launches below 16 steps) -- saved state byte for byte after every launch, a replay
+    forced by a full log (load 300 on 100 slots: a link collects 40 updates within a launch) -- and against the oracle's link
+    statistics."""
+    if STEP_KERNEL != "group":
+        pytest.skip("a test of the four-environments-per-wave kernel")
+    kw = dict(num_spectrum_resources=100, load=300, mean_service_holding_time=25, episode_length=300, seed=17,
+              bit_rates=[25, 50, 75, 100])
+    B = 10
+    outs = ("act_path", "act_slot", "accepted")
+    a = make_batched(nsfnet, kw, B, step_kernel="group")
+    os.environ["ORLG_NO_DEFER"] = "1"
+    try:
+        b = make_batched(nsfnet, kw, B, step_kernel="group")
+        ref_runs = [b.run("sap_ff", n, outputs=outs, auto_reset=True) for n in (700, 16, 333)]
+        assert b.last_kernel().startswith("orlg_rmsa_group_kernel<2,2>"), b.last_kernel()
+        sb = b.save_state()
+    finally:
+        del os.environ["ORLG_NO_DEFER"]
+    runs = [a.run("sap_ff", n, outputs=outs, auto_reset=True) for n in (700, 16, 333)]
+    assert a.last_kernel().startswith("orlg_rmsa_group_kernel<2,2,false,true>"), a.last_kernel()
+    for x, y in zip(runs, ref_runs):
+        for k in outs:
+            assert np.array_equal(x[k], y[k]), k
+    assert np.array_equal(a.save_state(), sb)
+    ls = a.link_stats()
+    for i in (0, 3, 9):
+        o = oracle_env_from_kwargs(nsfnet, kw, seed=17 + i)
+        o.run("sap_ff", 700 + 16 + 333, reset_on_done=True, fields=[])
+        ols = o.link_stats()
+        for name in ols:
+            assert np.array_equal(ls[name][i], ols[name]), (name, i)
+        o.close()
+    a.close()
+    b.close()
