@@ -732,14 +732,17 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
                     group_link_stats<W, FULL, false, DEFER>(lane, occ, lst, lint, tb, S, E, rec2->link, rel_now ? hops2 : 0, current_time,
                                                             sum_span, sum_gaps, comp_cur, sum_sh, 0.0, g_thr, g_comp, g_lu, llog, &need_replay);
                 if (DEFER && ballot(need_replay) != 0ull) {   // (a link's log never grows past ORLG_LLOG_FLUSH + 1 entries)
+                    SEC(14);  // link replay
                     group_link_replay(lane, lst, lint, tb, S, E, llog);
                     need_replay = false;
+                    SEC(11);
                 }
             }
             if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
         }
 
         if (DEFER && ballot(need_replay) != 0ull) {   // a link's log is filling up: every row works its logs off
+            SEC(14);  // link replay
             group_link_replay(lane, lst, lint, tb, S, E, llog);
             need_replay = false;
         }
@@ -767,6 +770,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         }
     }
 
+    SEC(14);  // link replay
     if (DEFER) group_link_replay(lane, lst, lint, tb, S, E, llog);   // (the state that leaves carries no pending updates)
     // ------------------------------------------------------------------ LDS -> HBM
     SEC(13);  // state store

@@ -1643,10 +1643,13 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
         lk0 = p.gn_link[4 * lnk]; lk1 = p.gn_link[4 * lnk + 1]; lk2 = p.gn_link[4 * lnk + 2];
         lkn = p.gn_nspans[lnk];
     }
+    // per hop only the interferer sum over the link's lit channels is wave-wide work; what follows from it -- the span's NLI
+    // and ASE power and its share of 1 / GSNR: ~100 instructions with two divisions -- is done for ALL hops at once, lane h =
+    // hop h, and the spans are then added hop by hop, span by span, as the reference adds them
+    double sp = 0.0;   // lane h: sum_phi of hop h
     for (int h = 0; h < hops; ++h) {
         const int link = (int)rec->link[h];
-        const double l_eff = readlane_d(lk0, h), ratio = readlane_d(lk1, h), e1 = readlane_d(lk2, h);
-        const int ns = __builtin_amdgcn_readlane(lkn, h);
+        const double ratio = readlane_d(lk1, h);
         // per interferer asinh(..) - asinh(..) - phi_mod (B / |df|) 5/3 l_eff / L, as calculate_osnr.py:33-45 sums them; one wave sum
         double sphi = 0.0;
 #pragma unroll
@@ -1654,10 +1657,19 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
             const bool lit = !((occ[__mul24(link, W) + w] >> lane) & 1ull);   // (A, B are 0 on channels that do not exist)
             sphi += lit ? (A[w] - (B[w] * ratio)) : 0.0;
         }
-        const double sum_phi = base + wave_add_f64(sphi);
-        const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sum_phi * bw;
+        const double tot = base + wave_add_f64(sphi);
+        if (lane == h) sp = tot;
+    }
+    double gv = 0.0;
+    {
+        const double l_eff = lk0, e1 = lk2;
+        const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sp * bw;
         const double power_ase = bw * h_plank * fc * e1 * nf;
-        const double g = 1 / (pw / (power_ase + power_nli_span));
+        if (lane < hops) gv = 1 / (pw / (power_ase + power_nli_span));
+    }
+    for (int h = 0; h < hops; ++h) {
+        const double g = readlane_d(gv, h);
+        const int ns = __builtin_amdgcn_readlane(lkn, h);
         for (int sx = 0; sx < ns; ++sx) acc += g;
     }
     return 10 * log10(1 / acc);

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "optical-rl-gym-qot-aware_amd")
 LIB = os.path.join(PKG, "liborlg_sections.so")
 NAMES = ["idle/ticket", "state load", "policy", "validate+provision", "stats@provision", "queue insert", "outputs",
-         "next arrival", "refill", "release scan", "release apply", "stats@release", "done/reset", "state store", "link cache init", ""]
+         "next arrival", "refill", "release scan", "release apply", "stats@release", "done/reset", "state store", "link replay", ""]
 
 
 def main():
