@@ -50,6 +50,7 @@ struct orlg_env {
     int group_wpb_hq, group_wave_bytes_hq;      // the same for launches that leave the release queue in HBM (orlg_rmsa_group_kernel<.., true>)
     int group_resident_hq[ORLG_GROUP_WAVES + 1];
     int group_resident_df[ORLG_GROUP_WAVES + 1];   // ... of the instantiation with the link statistics deferred
+    int group_df_lint, group_df_qtime, group_df_qdesc, group_df_wave_bytes, group_df_wpb;   // its LDS layout (no link-statistics slices)
     uint4 *llog;             // its log of link updates [B][E][64] (allocated with the first such launch)
     size_t group_lds_bytes;
     int num_cu;
@@ -280,12 +281,13 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     // launches of very few steps leave the release queue in HBM (the kernel's HBMQ instantiation): without the queue's slices an
     // environment takes half the LDS, and such a launch is bound by the waves a CU keeps resident
     const bool hq = p.n_steps <= ORLG_DIRECT_STEPS && e->group_wpb_hq > e->group_wpb;
-    const int wave_bytes = hq ? e->group_wave_bytes_hq : p.g_wave_bytes;
-    const int wpb_max = hq ? e->group_wpb_hq : e->group_wpb;
+    const bool df_ok = !hq && p.stats_level >= 2 && p.n_steps >= 16 && !getenv("ORLG_NO_DEFER") && e->group_df_wpb >= 1 &&
+                       !(p.out_mask & ((1 << ORLG_OUT_AVG_LINK_COMPACT) | (1 << ORLG_OUT_AVG_LINK_UTIL)));
+    const int wave_bytes = hq ? e->group_wave_bytes_hq : df_ok ? e->group_df_wave_bytes : p.g_wave_bytes;
+    const int wpb_max = hq ? e->group_wpb_hq : df_ok ? e->group_df_wpb : e->group_wpb;
     // long launches with full statistics whose outputs do not read the link statistics step by step: the instantiation that
     // logs the links' updates and works them off one link per lane (group_link_replay)
-    const bool df = !hq && p.stats_level >= 2 && p.n_steps >= 16 && !getenv("ORLG_NO_DEFER") &&
-                    !(p.out_mask & ((1 << ORLG_OUT_AVG_LINK_COMPACT) | (1 << ORLG_OUT_AVG_LINK_UTIL)));
+    const bool df = df_ok;
     int *resident = hq ? e->group_resident_hq : df ? e->group_resident_df : e->group_resident;
     rmsa_kernel_t k = pick_group(e->W, p.stats_level + (hq ? 4 : df ? 8 : 0));
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
@@ -319,6 +321,7 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     if (nblocks > resident[wpb]) nblocks = resident[wpb];
     OrlgParams q = p;
     q.llog = df ? e->llog : nullptr;
+    if (df) { q.g_lint = e->group_df_lint; q.g_qtime = e->group_df_qtime; q.g_qdesc = e->group_df_qdesc; }
     q.g_wave_bytes = wave_bytes;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
@@ -643,6 +646,16 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         e->group_lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)e->group_wpb * p.g_wave_bytes;
         for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = e->group_resident_hq[w] = e->group_resident_df[w] = 0;
         e->llog = nullptr;
+        {   // the instantiation that defers the link statistics keeps them in HBM: the same arrays without their slices
+            int gd = up16(p.g_occ + 4 * p.NW * 8);
+            e->group_df_lint = gd; gd = up16(gd + 4 * p.lint_stride * 4);
+            e->group_df_qtime = gd; gd = up16(gd + 4 * Q * 8);
+            e->group_df_qdesc = gd; gd = up16(gd + 4 * Q * 4);
+            e->group_df_wave_bytes = gd;
+            e->group_df_wpb = 0;
+            for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_df_wpb; cand--)
+                if ((size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)cand * gd <= 160 * 1024) e->group_df_wpb = cand;
+        }
         e->group_wave_bytes_hq = p.g_qtime;   // the region ends where the ring's slices would begin (they are the last arrays)
         e->group_wpb_hq = 0;
         for (int cand = ORLG_GROUP_WAVES; cand >= 1 && !e->group_wpb_hq; cand--)

@@ -218,7 +218,7 @@ DEV void group_link_replay(const int lane, double *lst, int32_t *lint, const Tab
         const int n = (int)((uint32_t)li >> 26);
         if (ballot(n > 0) == 0ull) continue;
         double s_util = 0.0, s_ef = 0.0, s_c = 0.0, s_lu = 0.0;
-        if (on) { s_util = lst[link]; s_ef = lst[E + link]; s_c = lst[2 * E + link]; s_lu = lst[3 * E + link]; }
+        if (on && n > 0) { s_util = lst[link]; s_ef = lst[E + link]; s_c = lst[2 * E + link]; s_lu = lst[3 * E + link]; }
         const uint4 *row = llog + __mul24(on ? link : 0, ORLG_LLOG_CAP);
         const int nmax = wave_max_i32(n);
         uint4 e_nx = make_uint4(0u, 0u, 0u, 0u);
@@ -333,7 +333,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         qtime = reinterpret_cast<double *>(wbase + p.g_qtime) + g * p.Q;
         qdesc = reinterpret_cast<uint32_t *>(wbase + p.g_qdesc) + g * p.Q;
     }
-    double *lst = reinterpret_cast<double *>(wbase + p.g_lstat) + g * 4 * p.E;
+    // (DEFER: the link statistics are touched by group_link_replay only, a few times per launch: they stay in HBM, and the 704
+    // bytes per environment they took of the LDS buy a twelfth wave per CU)
+    double *lst = DEFER ? nullptr : reinterpret_cast<double *>(wbase + p.g_lstat) + g * 4 * p.E;
     int32_t *lint = reinterpret_cast<int32_t *>(wbase + p.g_lint) + g * p.lint_stride;
 
     const int E = p.E, S = p.S, K = p.K, N = p.N, NBR = p.NBR, Q = p.Q, NW = p.NW;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     const int env0 = quad * ORLG_GE;
     const int nact = p.B - env0 < ORLG_GE ? p.B - env0 : ORLG_GE;
     quad_copy(wbase + p.g_occ, p.occ + (size_t)env0 * NW, nact * NW * 8, lane);
-    if (FULL) quad_copy(wbase + p.g_lstat, p.lstat + (size_t)env0 * 4 * E, nact * 4 * E * 8, lane);
+    if (FULL && !DEFER) quad_copy(wbase + p.g_lstat, p.lstat + (size_t)env0 * 4 * E, nact * 4 * E * 8, lane);
     // the bit-rate histograms are only ever incremented (and zeroed at an episode's end): they stay in HBM and take L2 atomics
     // without return -- 336 bytes of LDS per environment decide how many waves a CU keeps resident.  Every access
     // is an atomic, so that the updates of one address arrive at L2 in program order.
@@ -385,12 +387,13 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         if (!act) {
             const int gs_ = nact - 1;
             for (int i = gl; i < NW; i += ORLG_GL) occ[i] = (reinterpret_cast<u64 *>(wbase + p.g_occ) + gs_ * NW)[i];
-            if (FULL) for (int i = gl; i < 4 * E; i += ORLG_GL) lst[i] = (reinterpret_cast<double *>(wbase + p.g_lstat) + gs_ * 4 * E)[i];
+            if (FULL && !DEFER) for (int i = gl; i < 4 * E; i += ORLG_GL) lst[i] = (reinterpret_cast<double *>(wbase + p.g_lstat) + gs_ * 4 * E)[i];
             if (NET) for (int i = gl; i < p.lint_stride; i += ORLG_GL) lint[i] = (reinterpret_cast<int32_t *>(wbase + p.g_lint) + gs_ * p.lint_stride)[i];
         }
     }
-    // the link-update log of this row's environment (DEFER)
+    // the link-update log of this row's environment (DEFER), and its link statistics where they live: HBM
     uint4 *llog = DEFER ? p.llog + (size_t)env * E * ORLG_LLOG_CAP : nullptr;
+    if (DEFER) lst = p.lstat + (size_t)env * 4 * E;
     bool need_replay = false;
     const OrlgEnvScalars *gs = p.scal + env;
     double current_time = gs->current_time, req_arrival = gs->req_arrival, req_holding = gs->req_holding;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         const int env0 = quad * ORLG_GE;
         const int nact = p.B - env0 < ORLG_GE ? p.B - env0 : ORLG_GE;
         quad_copy(p.occ + (size_t)env0 * NW, wbase + p.g_occ, nact * NW * 8, lane);
-        if (FULL) quad_copy(p.lstat + (size_t)env0 * 4 * E, wbase + p.g_lstat, nact * 4 * E * 8, lane);
+        if (FULL && !DEFER) quad_copy(p.lstat + (size_t)env0 * 4 * E, wbase + p.g_lstat, nact * 4 * E * 8, lane);
         if (NET) quad_copy(p.lint + (size_t)env0 * p.lint_stride, wbase + p.g_lint, nact * p.lint_stride * 4, lane);
     }
     if (act) {
