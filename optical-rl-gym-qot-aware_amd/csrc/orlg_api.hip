@@ -346,7 +346,12 @@ static bool group_kernel_serves(const orlg_env *e, const OrlgParams &p) {
 
 static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
     const bool ff = p.mode == ORLG_MODE_STEP && p.K <= 8 && (p.policy == ORLG_POLICY_SP || p.policy == ORLG_POLICY_SAP);
-    rmsa_kernel_t k = ff ? pick_rmsa_ff(e->W, p.stats_level) : pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
+    // long launches with full statistics whose outputs do not read the link statistics step by step: the instantiation that logs the
+    // links' updates and works them off one link per lane (link_replay) -- as launch_rmsa_group
+    const bool df = p.mode == ORLG_MODE_STEP && p.stats_level >= 2 && p.n_steps >= 16 && !getenv("ORLG_NO_DEFER") &&
+                    !(p.out_mask & ((1 << ORLG_OUT_AVG_LINK_COMPACT) | (1 << ORLG_OUT_AVG_LINK_UTIL)));
+    rmsa_kernel_t k = df ? pick_wave(e->W, ff ? ORLG_KIND_STEP_FF_DF : ORLG_KIND_STEP_DF, p.stats_level)
+                         : ff ? pick_rmsa_ff(e->W, p.stats_level) : pick_rmsa(e->W, p.stats_level, p.mode == ORLG_MODE_STEP);
     if (!k) return fail(ORLG_ERR_INVALID, "no kernel for W=%d", e->W);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)e->lds_block_bytes));
@@ -361,16 +366,21 @@ static int launch_rmsa(orlg_env *e, const OrlgParams &p) {
     if (group_kernel_serves(e, p)) return launch_rmsa_group(e, p);
     int nblocks = (p.B + wpb - 1) / wpb;
     if (nblocks > e->resident_blocks) nblocks = e->resident_blocks;
+    if (df && !e->llog) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->llog), (size_t)p.B * p.E * 64 * sizeof(uint4)));
+        e->bufs.push_back(e->llog);
+    }
     OrlgParams q = p;
+    q.llog = df ? e->llog : nullptr;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = (p.mode != ORLG_MODE_STEP || p.n_steps <= 16) ? 1u : 0u;
     if (!q.ticket_stride) e->ticket_base += (uint32_t)p.B;  // waves * 1 static environment + (B - waves) tickets + one failing draw per wave
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, e->lds_block_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
-    snprintf(e->last_kernel, sizeof(e->last_kernel), "%s<%d,%d> grid=%d block=%d lds=%zu",
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "%s<%d,%d%s> grid=%d block=%d lds=%zu",
              ff ? "orlg_rmsa_kernel_ff" : (p.mode == ORLG_MODE_STEP ? "orlg_rmsa_kernel" : "orlg_rmsa_reset_kernel"), e->W, p.stats_level,
-             nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
+             df ? ",true" : "", nblocks, ORLG_WAVE * wpb, e->lds_block_bytes);
     return ORLG_OK;
 }
 

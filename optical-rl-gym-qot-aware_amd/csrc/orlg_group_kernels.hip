@@ -79,8 +79,6 @@ ORLG_SEG_REDUCE(seg_max, ORLG_OP_MAX)
 // entries in the upper bits of the link's span cache, and group_link_replay works the logs off with ONE LINK PER LANE, sixteen
 // links of an environment at a time, every lane through its own link's events in their order -- the same operations on the
 // same values, so the same bits.
-#define ORLG_LLOG_CAP 64      // logged updates per (environment, link) between two replays (6-bit count)
-#define ORLG_LLOG_FLUSH 40    // a link that reaches this many asks for a replay at the end of the step
 template <int W, bool LINKF, bool GRAPH, bool DEFER = false>
 DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint8_t *links,
                           int nlinks, double now, int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr,
@@ -203,54 +201,8 @@ DEV void group_link_stats(const int lane, u64 *occ, double *lst, int32_t *lint, 
     }
 }
 
-// The logged link updates of the wave's four environments, worked off: lane gl of a row = link gl (+ 16, + 32, ...) of the row's
-// environment; every lane runs through its link's entries in their order with the link's four statistics in registers -- the
-// float64 operations of _update_link_stats (rmsa_env.py:562-641) as group_link_stats does them, one update after the other.
 DEV void group_link_replay(const int lane, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint4 *llog) {
-    const int gl = lane & 15;
-    // the entries other lanes of this wave logged: the stores only have to be complete (same CU)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int l0 = 0; l0 < E; l0 += ORLG_GL) {
-        const int link = l0 + gl;
-        const bool on = link < E;
-        const int li = on ? lint[link] : 0;
-        const int n = (int)((uint32_t)li >> 26);
-        if (ballot(n > 0) == 0ull) continue;
-        double s_util = 0.0, s_ef = 0.0, s_c = 0.0, s_lu = 0.0;
-        if (on && n > 0) { s_util = lst[link]; s_ef = lst[E + link]; s_c = lst[2 * E + link]; s_lu = lst[3 * E + link]; }
-        const uint4 *row = llog + __mul24(on ? link : 0, ORLG_LLOG_CAP);
-        const int nmax = wave_max_i32(n);
-        uint4 e_nx = make_uint4(0u, 0u, 0u, 0u);
-        if (n > 0) e_nx = row[0];
-        for (int k = 0; k < nmax; ++k) {
-            const uint4 ev = e_nx;
-            if (k + 1 < n) e_nx = row[k + 1];   // (the next entry is requested before this one is worked on)
-            if (k < n) {
-                const int freec = (int)(ev.x & 0x3ffu), max_empty = (int)((ev.x >> 10) & 0x3ffu), span = (int)(ev.x >> 20), U = (int)ev.y;
-                const double now = __hiloint2double((int)ev.w, (int)ev.z);
-                if (now > 0) {
-                    const double ynow = recip_refine(now);
-                    const double cur0 = tb.div_s[S - freec];  // (S - free) / S
-                    double cur1 = 0.0, cur2 = 0.0;
-                    if (freec > 0) {
-                        cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
-                        cur2 = U > 1 ? ORLG_FDIV((double)span, (double)(S - freec)) * tb.inv_k[U] : 1.0;
-                    }
-                    const double time_diff = now - s_lu;
-                    s_util = div_by((s_util * s_lu) + (cur0 * time_diff), now, ynow);
-                    s_ef = div_by((s_ef * s_lu) + (cur1 * time_diff), now, ynow);
-                    s_c = div_by((s_c * s_lu) + (cur2 * time_diff), now, ynow);
-                }
-                s_lu = now;
-            }
-        }
-        if (on && n > 0) {
-            lst[link] = s_util; lst[E + link] = s_ef; lst[2 * E + link] = s_c; lst[3 * E + link] = s_lu;
-            lint[link] = li & 0x03ffffff;
-        }
-    }
-    wave_sync();
+    link_replay<ORLG_GL>(lane, lst, lint, tb, S, E, llog);
 }
 
 // set (release) or clear (provision) the window [s, s+n) on every link of a row's path; hops = 0: the row does not take part

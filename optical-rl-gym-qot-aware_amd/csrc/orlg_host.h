@@ -47,7 +47,8 @@ void orlg_err_word_destroy(OrlgErrWord *w);
 // Every unit exports one lookup per word count W; a W the library was not built for resolves to a null (weak) symbol.
 typedef void (*orlg_rmsa_kernel_t)(const OrlgParams);
 typedef void (*orlg_masks_kernel_t)(const OrlgParams, int, int, int, uint64_t *, int32_t *);
-enum { ORLG_KIND_STEP = 0, ORLG_KIND_STEP_FF = 1, ORLG_KIND_RESET = 2, ORLG_KIND_OBS = 3, ORLG_KIND_GROUP = 4 };
+enum { ORLG_KIND_STEP = 0, ORLG_KIND_STEP_FF = 1, ORLG_KIND_RESET = 2, ORLG_KIND_OBS = 3, ORLG_KIND_GROUP = 4,
+       ORLG_KIND_STEP_DF = 5, ORLG_KIND_STEP_FF_DF = 6 };   // _DF: full statistics with the links' float64 part deferred (link_replay)
 #define ORLG_FOR_EACH_W(X) X(1) X(2) X(3) X(4) X(5) X(6) X(8)
 #define ORLG_DECL_W(n)                                                                           \
     orlg_rmsa_kernel_t orlg_wave_kernel_W##n(int kind, int stats) __attribute__((weak));          \

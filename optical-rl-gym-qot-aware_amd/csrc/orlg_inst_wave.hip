@@ -16,6 +16,10 @@ static orlg_rmsa_kernel_t pick_stats(int kind, int stats) {
             return stats == 0 ? orlg_rmsa_kernel<W, 0> : stats == 1 ? orlg_rmsa_kernel<W, 1> : orlg_rmsa_kernel<W, 2>;
         case ORLG_KIND_STEP_FF:  // first-fit policies only (k <= 8)
             return stats == 0 ? orlg_rmsa_kernel_ff<W, 0> : stats == 1 ? orlg_rmsa_kernel_ff<W, 1> : orlg_rmsa_kernel_ff<W, 2>;
+        case ORLG_KIND_STEP_DF:
+            return stats == 2 ? orlg_rmsa_kernel<W, 2, true> : nullptr;
+        case ORLG_KIND_STEP_FF_DF:
+            return stats == 2 ? orlg_rmsa_kernel_ff<W, 2, true> : nullptr;
         case ORLG_KIND_RESET:
             return stats == 0 ? orlg_rmsa_reset_kernel<W, 0> : stats == 1 ? orlg_rmsa_reset_kernel<W, 1> : orlg_rmsa_reset_kernel<W, 2>;
         case ORLG_KIND_OBS:

@@ -685,10 +685,66 @@ DEV u64 run_starts(u64 x, int n, int w) {
     return ((u64)hi << 32) | lo;
 }
 
-template <int W, bool LINKF, bool GRAPH>
+#define ORLG_LLOG_CAP 64      // logged updates per (environment, link) between two replays (6-bit count)
+#define ORLG_LLOG_FLUSH 40    // a link that reaches this many asks for a replay
+// The logged link updates (DEFER instantiations), worked off: lane gl of a row of GL lanes = link gl (+ GL, ...) of the row's
+// environment (GL = 16: four environments per wave, GL = 64: one); every lane runs through its link's entries in their order with the link's four statistics in registers -- the
+// float64 operations of _update_link_stats (rmsa_env.py:562-641) as link_stats_update / group_link_stats do them, one update after the other.
+template <int GL>
+DEV void link_replay(const int lane, double *lst, int32_t *lint, const Tab &tb, int S, int E, const uint4 *llog) {
+    const int gl = lane & (GL - 1);
+    // the entries other lanes of this wave logged: the stores only have to be complete (same CU)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int l0 = 0; l0 < E; l0 += GL) {
+        const int link = l0 + gl;
+        const bool on = link < E;
+        const int li = on ? lint[link] : 0;
+        const int n = (int)((uint32_t)li >> 26);
+        if (ballot(n > 0) == 0ull) continue;
+        double s_util = 0.0, s_ef = 0.0, s_c = 0.0, s_lu = 0.0;
+        if (on && n > 0) { s_util = lst[link]; s_ef = lst[E + link]; s_c = lst[2 * E + link]; s_lu = lst[3 * E + link]; }
+        const uint4 *row = llog + __mul24(on ? link : 0, ORLG_LLOG_CAP);
+        const int nmax = wave_max_i32(n);
+        uint4 e_nx = make_uint4(0u, 0u, 0u, 0u);
+        if (n > 0) e_nx = row[0];
+        for (int k = 0; k < nmax; ++k) {
+            const uint4 ev = e_nx;
+            if (k + 1 < n) e_nx = row[k + 1];   // (the next entry is requested before this one is worked on)
+            if (k < n) {
+                const int freec = (int)(ev.x & 0x3ffu), max_empty = (int)((ev.x >> 10) & 0x3ffu), span = (int)(ev.x >> 20), U = (int)ev.y;
+                const double now = __hiloint2double((int)ev.w, (int)ev.z);
+                if (now > 0) {
+                    const double ynow = recip_refine(now);
+                    const double cur0 = tb.div_s[S - freec];  // (S - free) / S
+                    double cur1 = 0.0, cur2 = 0.0;
+                    if (freec > 0) {
+                        cur1 = 1.0 - ORLG_FDIV((double)max_empty, (double)freec);
+                        cur2 = U > 1 ? ORLG_FDIV((double)span, (double)(S - freec)) * tb.inv_k[U] : 1.0;
+                    }
+                    const double time_diff = now - s_lu;
+                    s_util = div_by((s_util * s_lu) + (cur0 * time_diff), now, ynow);
+                    s_ef = div_by((s_ef * s_lu) + (cur1 * time_diff), now, ynow);
+                    s_c = div_by((s_c * s_lu) + (cur2 * time_diff), now, ynow);
+                }
+                s_lu = now;
+            }
+        }
+        if (on && n > 0) {
+            lst[link] = s_util; lst[E + link] = s_ef; lst[2 * E + link] = s_c; lst[3 * E + link] = s_lu;
+            lint[link] = li & 0x03ffffff;
+        }
+    }
+    wave_sync();
+}
+
+template <int W, bool LINKF, bool GRAPH, bool DEFER = false>
 DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t *links, int nlinks, double now,
-                           int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr) {
+                           int &sum_span, int &sum_gaps, double &comp_cur, int sum_sh, double cur_thr, uint4 *llog = nullptr) {
+    // DEFER (see group_link_stats, orlg_group_kernels.hip): the links' float64 recurrences are not done here -- what they consume is
+    // logged per link and link_replay works the logs off with one link per lane; the graph statistics stay (one chain per environment)
     static_assert(W <= 8, "a link group is 8 lanes");
+    bool need_replay = false;
     constexpr int HPC = 8;  // links per chunk: lane = link slot * 8 + word
     const int lane = wv.lane;
     const int hl = lane >> 3, w = lane & 7;
@@ -754,7 +810,20 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
         if (link_lane) {
             int nspan = U > 1 ? lmax - lmin : 0, ngaps = U > 1 ? U - 1 : 0;
             int old = wv.lint[link];
-            wv.lint[link] = nspan | (ngaps << 16);
+            int cnt = 0;
+            if (LINKF && DEFER) {
+                cnt = (int)((uint32_t)old >> 26);
+                const int max_empty = (F > 1 && !(F == 2 && first_free && last_free)) ? ml : 0;
+                if (cnt < ORLG_LLOG_CAP - 1) {
+                    llog[__mul24(link, ORLG_LLOG_CAP) + cnt] =
+                        make_uint4((uint32_t)freec | ((uint32_t)max_empty << 10) | ((uint32_t)(lmax - lmin) << 20), (uint32_t)U,
+                                   (uint32_t)__double2loint(now), (uint32_t)__double2hiint(now));
+                    cnt += 1;
+                }
+                if (cnt >= ORLG_LLOG_FLUSH) need_replay = true;
+                old &= 0x03ffffff;
+            }
+            wv.lint[link] = nspan | (ngaps << 16) | (cnt << 26);
             dspan = nspan - (old & 0xffff);
             dgaps = ngaps - (old >> 16);
         }
@@ -765,8 +834,8 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
         const bool graph_now = GRAPH && last_chunk;
         if (graph_now) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
         // ---- floats: links on their group's first lane, graph throughput / compactness on lanes 62 / 63
-        if ((LINKF || graph_now) && now > 0) {
-            const bool is_link = LINKF && link_lane;
+        if (((LINKF && !DEFER) || graph_now) && now > 0) {
+            const bool is_link = LINKF && !DEFER && link_lane;
             const bool is_graph = graph_now && lane >= 62;
             if (is_link || is_graph) {
                 double *l_util = wv.lst, *l_ef = wv.lst + E, *l_c = wv.lst + 2 * E, *l_lu = wv.lst + 3 * E;
@@ -799,11 +868,12 @@ DEV void link_stats_update(Wave &wv, const Tab &tb, int S, int E, const uint8_t 
                 }
             }
         }
-        if (LINKF && link_lane) wv.lst[3 * E + link] = now;
+        if (LINKF && !DEFER && link_lane) wv.lst[3 * E + link] = now;
         wave_sync();
         if (graph_now && lane == 0) wv.wsc->g_lu = now;
         wave_sync();
     }
+    if (DEFER && ballot(need_replay) != 0ull) link_replay<64>(lane, wv.lst, wv.lint, tb, S, E, llog);
 }
 
 // set (release) or clear (provision) the window [s, s+n) on every link of a path
@@ -851,7 +921,7 @@ __device__ unsigned long long orlg_sections[16];
 // same body without the policy / provisioning part, under its own name so that kernel statistics keep the two apart.
 // FF: an instantiation that only knows the first-fit policies (shortest path / shortest available path, k <= 8): the other
 // policies' code -- and the registers it pins -- is gone from the kernel the headline workload runs.
-template <int W, int STATS, bool STEPK, bool FF = false>
+template <int W, int STATS, bool STEPK, bool FF = false, bool DEFER = false>
 DEV void rmsa_body(const OrlgParams &p) {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef ORLG_SHAPE_ASSUME
@@ -1129,8 +1199,8 @@ DEV void rmsa_body(const OrlgParams &p) {
                         wave_sync();
                         cur_thr = (double)wv.wsc->sum_bitrate_running;
                         // per-link stats of the path's links, then _update_network_stats (rmsa_env.py:494-499)
-                        link_stats_update<W, FULL, true>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
-                                                         comp_cur, sum_sh, cur_thr);
+                        link_stats_update<W, FULL, true, DEFER>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
+                                                                comp_cur, sum_sh, cur_thr, DEFER ? kernarg_params()->llog + (size_t)env * E * ORLG_LLOG_CAP : nullptr);
                     }
                     accepted = true;
                     SEC(5);  // queue insert
@@ -1290,8 +1360,8 @@ DEV void rmsa_body(const OrlgParams &p) {
                 sum_sh -= n * hops;
                 SEC(11);  // statistics at release
                 if (NET)
-                    link_stats_update<W, FULL, false>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
-                                                      comp_cur, sum_sh, 0.0);
+                    link_stats_update<W, FULL, false, DEFER>(wv, tb, S, E, rec->link, hops, current_time, sum_span, sum_gaps,
+                                                             comp_cur, sum_sh, 0.0, DEFER ? kernarg_params()->llog + (size_t)env * E * ORLG_LLOG_CAP : nullptr);
                 released = true;
             }
             if (NET && released) comp_cur = network_compactness(sum_span, sum_sh, sum_gaps, E);
@@ -1321,6 +1391,8 @@ DEV void rmsa_body(const OrlgParams &p) {
     // ------------------------------------------------------------------ LDS -> HBM (coalesced)
     SEC(13);  // state store
     wave_sync();
+    // (the state that leaves carries no pending link updates)
+    if (DEFER) link_replay<64>(lane, wv.lst, wv.lint, tb, S, E, kernarg_params()->llog + (size_t)env * E * ORLG_LLOG_CAP);
     {
         KernargParams kp = kernarg_params();
         if ((NW & 1) == 0) {
@@ -1367,13 +1439,13 @@ DEV void rmsa_body(const OrlgParams &p) {
     SEC_FLUSH;
 }
 
-template <int W, int STATS>
+template <int W, int STATS, bool DEFER = false>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel(const OrlgParams p) {
-    rmsa_body<W, STATS, true>(p);
+    rmsa_body<W, STATS, true, false, DEFER>(p);
 }
-template <int W, int STATS>
+template <int W, int STATS, bool DEFER = false>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_kernel_ff(const OrlgParams p) {
-    rmsa_body<W, STATS, true, true>(p);
+    rmsa_body<W, STATS, true, true, DEFER>(p);
 }
 template <int W, int STATS>
 __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_rmsa_reset_kernel(const OrlgParams p) {
