@@ -14,6 +14,7 @@ the reference's functions run unchanged on these classes as well (same names, sa
 from __future__ import annotations
 
 import math
+from collections import defaultdict
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -141,7 +142,41 @@ class RMSAEnv:
         self.observation_space = None
         self.action_space.seed(self.rand_seed)
         self.current_service: Optional[Service] = None
+        # bookkeeping the reference keeps beside the simulation (no info key reads it): kept here, on the host, from what a step
+        # returns -- rmsa_env.py:185-196 (shape (k + 1, S + 1) at construction), :118-128
+        shape = (self.k_paths + 1, self.num_spectrum_resources + 1)
+        self.actions_output = np.zeros(shape, dtype=int)
+        self.episode_actions_output = np.zeros(shape, dtype=int)
+        self.actions_taken = np.zeros(shape, dtype=int)
+        self.episode_actions_taken = np.zeros(shape, dtype=int)
+        if self.bit_rate_selection == "discrete":
+            self.slots_requested_histogram = defaultdict(int)
+            self.episode_slots_requested_histogram = defaultdict(int)
+            self.slots_provisioned_histogram = defaultdict(int)
+            self.episode_slots_provisioned_histogram = defaultdict(int)
         self._sync()
+        self._count_request()
+
+    def _count_request(self):
+        """``_next_service`` (rmsa_env.py:676-686): the histogram of slots requested, assuming the shortest path."""
+        if self.bit_rate_selection == "discrete":
+            slots = self.get_number_slots(self._candidates[0])
+            self.slots_requested_histogram[slots] += 1
+            self.episode_slots_requested_histogram[slots] += 1
+
+    def _reset_bookkeeping(self, only_episode_counters):
+        """``reset`` (rmsa_env.py:343-389): the episode arrays are re-created (with the reject action's shape), the pending
+        request counted again; the arrays of the whole run are never cleared."""
+        shape = (self.k_paths + self.reject_action, self.num_spectrum_resources + self.reject_action)
+        self.episode_actions_output = np.zeros(shape, dtype=int)
+        self.episode_actions_taken = np.zeros(shape, dtype=int)
+        if self.bit_rate_selection == "discrete":
+            self.episode_slots_requested_histogram = defaultdict(int)
+            self.episode_slots_provisioned_histogram = defaultdict(int)
+            if only_episode_counters:
+                self.episode_slots_requested_histogram[self.get_number_slots(self._candidates[0])] += 1
+        if not only_episode_counters:
+            self._count_request()   # (the full reset ends with _next_service)
 
     def _sync(self):
         """Refresh the host mirror of the pending request, the counters and the per-path masks."""
@@ -236,7 +271,12 @@ class RMSAEnv:
             raise RuntimeError("reset() of a view into a larger batch would reset every env: use the batched API")
         self._batched.reset(only_episode_counters)
         self._sync()
+        self._reset_bookkeeping(only_episode_counters)
         return self.observation()
+
+    def _resolved_action(self, action, r):
+        """(path, initial_slot) as RMSAEnv.step sees them"""
+        return int(action[0]), int(action[1])
 
     def _device_step(self, action):
         path, initial_slot = int(action[0]), int(action[1])
@@ -250,13 +290,25 @@ class RMSAEnv:
         if self._batched.batch_size != 1:
             raise RuntimeError("step() needs a batch-1 environment: use the batched API for B > 1")
         served = self.current_service
+        candidates = self._candidates
         r = self._device_step(action)
         served.accepted = bool(r["accepted"][0, 0])
+        # rmsa_env.py:226, 261-267, 271, 509: every action counted, the accepted ones again -- and their slots twice (step and
+        # _provision_path both add one)
+        path, initial_slot = self._resolved_action(action, r)
+        self.actions_output[path, initial_slot] += 1
+        if served.accepted:
+            self.actions_taken[path, initial_slot] += 1
+            if self.bit_rate_selection == "discrete":
+                self.slots_provisioned_histogram[self.get_number_slots(candidates[path])] += 2
+        else:
+            self.actions_taken[self.k_paths, self.num_spectrum_resources] += 1
         info = self._info(float(r["network_compactness"][0, 0]), float(r["network_compactness_difference"][0, 0]),
                           float(r["avg_link_compactness"][0, 0]), float(r["avg_link_utilization"][0, 0]))
         reward = r["reward"][0, 0]
         reward = int(reward) if float(reward).is_integer() else float(reward)
         self._sync()
+        self._count_request()
         self._last_served = served
         return self.observation(), reward, bool(r["done"][0, 0]), info
 
@@ -336,7 +388,11 @@ class DeepRMSAEnv(RMSAEnv):
         return self._batched.run("deeprmsa_external", 1, actions=np.array([int(action)], np.int32),
                                  outputs=("accepted", "done", "reward", "network_compactness",
                                           "network_compactness_difference", "avg_link_compactness",
-                                          "avg_link_utilization"))
+                                          "avg_link_utilization", "act_path", "act_slot"))
+
+    def _resolved_action(self, action, r):
+        """``deeprmsa_env.py:48-58``: the (route, first slot of the block) the action stands for, (k, S) for a rejection"""
+        return int(r["act_path"][0, 0]), int(r["act_slot"][0, 0])
 
     def _get_route_block_id(self, action: int) -> Tuple[int, int]:
         return action // self.j, action % self.j

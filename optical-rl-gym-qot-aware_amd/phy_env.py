@@ -85,6 +85,8 @@ class PhyRMSAEnv:
         self.bit_rates = list(b.bit_rates)
         self.channel_state = _ChannelState(self)
         self.services_accepted_virtual = 0
+        # BVT counters per band and node pair (phy_rmsa_env.py:153-156: 1 = C band, 0 = L band, 2 = S band), kept on the host
+        self.bvts = np.zeros((3, ft.num_nodes, ft.num_nodes), dtype=int)
         self.current_service: Optional[Service] = None
         self._sync()
 
@@ -199,6 +201,15 @@ class PhyRMSAEnv:
         r = self._batched.run("external", 1, act_path=ap, act_channels=ac,
                               outputs=("accepted", "done", "number_cuts_total", "rss_total_metric", "defrag_counters"))
         served.accepted = bool(r["accepted"][0, 0])
+        if served.accepted and path <= 10:
+            # _provision_path (phy_rmsa_env.py:603-608): one transceiver per channel lit, by the band of its index -- with the
+            # reference's bounds (index == number_spectrum_channels counts as C band, 2 * number_spectrum_channels as L band)
+            n, ns = self.num_spectrum_channels, self.number_spectrum_channels_s_band
+            for ch in channels:
+                c0 = int(ch[0])
+                band = 1 if c0 <= n else 0 if c0 <= 2 * n else 2 if c0 < 2 * n + ns else None
+                if band is not None:
+                    self.bvts[band][served.source_id][served.destination_id] += 1
         b = self._batched
         c = {k: int(v[0]) for k, v in b.counters().items()}
         nxt = int(b.requests()[0]["bit_rate"])

@@ -338,6 +338,77 @@ def gen_seed():
     print("seed_rmsa_nsfnet_s10: accepted", int(r[:, 7].sum()), "of 120; arrival[41] =", r[41, 3])
 
 
+def _hist_rows(d):
+    """defaultdict(int) -> sorted (key, count) rows"""
+    return np.array(sorted((int(k), int(v)) for k, v in d.items()), dtype=np.int64).reshape(-1, 2)
+
+
+def gen_bookkeeping():
+    """The arrays the reference keeps beside the simulation and no info key reads: actions_output / actions_taken
+    (rmsa_env.py:185-196, 226, 261, 271; the episode_ twins are only ever re-zeroed: :348-360), slots_requested_histogram
+    (:685-686, 387) and slots_provisioned_histogram with its double increment (:265-267 and 509), and PhyRMSAEnv's BVT counters
+    (phy_rmsa_env.py:153-156, 603-608).  One RMSA run with random in- and out-of-range actions across episode resets and one
+    PhyRMSA run: the action traces and the arrays after the last step."""
+    from optical_rl_gym.envs import rmsa_env as R
+    from optical_rl_gym.envs import phy_rmsa_env as P
+    out = {}
+    topo = load_pickled_topology(TOPOLOGIES["nsfnet_chen_5-paths_6-modulations"])
+    kw = dict(RMSA_BASE, seed=13, allow_rejection=True, load=40, episode_length=250)
+    env = R.RMSAEnv(topology=topo, **kw)
+    arng = np.random.default_rng(5)
+    k, S = env.k_paths, env.num_spectrum_resources
+    acts, acc = [], []
+    for t in range(900):
+        if t % 3 == 0:
+            a = (int(arng.integers(0, k + 1)), int(arng.integers(0, S + 1)))
+        else:
+            a = R.shortest_available_path_first_fit(env)
+        s = env.current_service
+        _, _, done, _ = env.step(a)
+        acts.append((int(a[0]), int(a[1]))); acc.append(bool(s.accepted))
+        if done:
+            env.reset()
+    out["rmsa_actions"] = np.array(acts, np.int32)
+    out["rmsa_accepted"] = np.array(acc, np.uint8)
+    for name in ("actions_output", "actions_taken", "episode_actions_output", "episode_actions_taken"):
+        out["rmsa_" + name] = np.asarray(getattr(env, name), dtype=np.int64)
+    for name in ("slots_requested_histogram", "episode_slots_requested_histogram", "slots_provisioned_histogram",
+                 "episode_slots_provisioned_histogram"):
+        out["rmsa_" + name] = _hist_rows(getattr(env, name))
+    meta = dict(rmsa=dict(topology="nsfnet_chen_5-paths_6-modulations", env_kwargs=_jsonable(kw), steps=900))
+
+    tab = "us14_k3"
+    pkw = dict(PHY_BASE, seed=21, load=1400)
+    ptopo = load_pickled_topology(TOPOLOGIES[PHY_TABLES[tab][2]])
+    conn, mod, gsnr = load_phy_tables(tab)
+    penv = P.PhyRMSAEnv(topology=ptopo, modulation_level=mod, connections_detail=conn, gsnr=gsnr, **pkw)
+    MAXCH = 12
+    paths, chans, used, free, cap, pacc = [], [], [], [], [], []
+    for t in range(500):
+        a = P.phy_aware_bmff_rmsa(penv)     # (bmff consults the virtual layer: physical and virtual acceptances mix)
+        chosen = [tuple(c) for c in a[1]]
+        s = penv.current_service
+        _, _, done, _, _ = penv.step(a)
+        row_c, row_u, row_f, row_k = [-1] * MAXCH, [0.0] * MAXCH, [0.0] * MAXCH, [0] * MAXCH
+        for i, c in enumerate(chosen):
+            row_c[i], row_u[i], row_f[i], row_k[i] = int(c[0]), float(c[1]), float(c[2]), int(c[3])
+        paths.append(int(a[0])); chans.append(row_c); used.append(row_u); free.append(row_f); cap.append(row_k)
+        pacc.append(bool(s.accepted))
+        if done:
+            penv.reset()
+    out["phy_act_path"] = np.array(paths, np.int32)
+    out["phy_channels"] = np.array(chans, np.int16)
+    out["phy_ch_used"] = np.array(used); out["phy_ch_free"] = np.array(free); out["phy_ch_cap"] = np.array(cap, np.int16)
+    out["phy_accepted"] = np.array(pacc, np.uint8)
+    out["phy_bvts"] = np.asarray(penv.bvts, dtype=np.int64)
+    meta["phy"] = dict(topology=PHY_TABLES[tab][2], tables=tab, env_kwargs=_jsonable(pkw), policy="bmff", steps=500)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "bookkeeping.npz"), **out)
+    print("bookkeeping: rmsa accepted", int(out["rmsa_accepted"].sum()), "of 900, actions_taken sum", int(out["rmsa_actions_taken"].sum()),
+          "slots_provisioned", out["rmsa_slots_provisioned_histogram"].tolist(), "| phy accepted", int(out["phy_accepted"].sum()),
+          "bvts", out["phy_bvts"].sum(axis=(1, 2)).tolist())
+
+
 # --------------------------------------------------------------------------- RMSA wrappers
 def gen_wrappers():
     """SimpleMatrixObservation (rmsa_env.py:940-971) and PathOnlyFirstFitAction (:974-1008) on RMSA-v0."""
@@ -673,7 +744,7 @@ def main():
     install_gym_stub()
     import optical_rl_gym  # noqa: F401  (registers env ids)
 
-    todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "seed", "deeprmsa", "phy", "osnr"]
+    todo = [args.only] if args.only else ["topologies", "rmsa", "wrappers", "seed", "bookkeeping", "deeprmsa", "phy", "osnr"]
     for what in todo:
         fn = globals().get("gen_" + what)
         if what == "phy" and args.case:

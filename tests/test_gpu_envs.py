@@ -138,3 +138,34 @@ def test_make_by_registry_id(nsfnet):
     obs, reward, done, info = env.step(pkg.shortest_available_path_first_fit(env))
     assert reward in (0, 1) and "service_blocking_rate" in info
     env.close()
+
+
+def test_rmsa_view_bookkeeping_arrays():
+    """actions_output / actions_taken and the slots histograms (rmsa_env.py:185-196, 226, 261-271, 509, 685-686; the episode_
+    twins of the action arrays are only ever re-created by reset(): :348-360) -- no info key reads them; the view keeps them on
+    the host.  The reference's run (tests/golden/bookkeeping.npz: 900 steps, every third action random incl. out-of-range ones =
+    rejections, reset() at the episode ends) replayed action by action."""
+    import json
+    import os
+    import optical_rl_gym_amd as pkg
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "bookkeeping.npz"))
+    meta = json.loads(str(z["meta"]))["rmsa"]
+    env = pkg.RMSAEnv(topology=load_topology(meta["topology"]), **meta["env_kwargs"])
+    for t in range(meta["steps"]):
+        a = (int(z["rmsa_actions"][t, 0]), int(z["rmsa_actions"][t, 1]))
+        if t % 3:
+            assert a == pkg.shortest_available_path_first_fit(env), t
+        s = env.current_service
+        _, _, done, _ = env.step(a)
+        assert s.accepted == bool(z["rmsa_accepted"][t]), t
+        if done:
+            env.reset()
+    for name in ("actions_output", "actions_taken", "episode_actions_output", "episode_actions_taken"):
+        got = getattr(env, name)
+        assert got.shape == z["rmsa_" + name].shape and np.array_equal(got, z["rmsa_" + name]), name
+    for name in ("slots_requested_histogram", "episode_slots_requested_histogram", "slots_provisioned_histogram",
+                 "episode_slots_provisioned_histogram"):
+        got = np.array(sorted((int(k), int(v)) for k, v in getattr(env, name).items()), dtype=np.int64).reshape(-1, 2)
+        assert np.array_equal(got, z["rmsa_" + name]), name
+    env.close()
