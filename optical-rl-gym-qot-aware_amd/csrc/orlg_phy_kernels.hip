@@ -1610,25 +1610,26 @@ DEV void phy_defragmentation(const OrlgPhyParams &p, const PhyTab &tb, u64 *occ,
 // the link has lit (the reference's per-interferer sum, re-associated: ~1e-15 relative); the spans of a link are equal, their
 // contribution is added span by span like the reference does.
 template <int W>
-DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *rec, const uint8_t *mrow, int ch, int lane) {
+DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *rec, int mrow_off, int ch_v, int lane SEC_PARAMS) {
+    SEC(8);   // (section profile of the check: table rows | 11 hop sums | 12 span powers | 14 logarithm)
     const double beta_2 = -21.3e-27, gamma = 1.3e-3, h_plank = 6.626e-34, pi = 3.141592653589793;
+    // the channel and the table row are wave-uniform, and the compiler has to know it: as values of lanes (they come out of LDS)
+    // every table address was a 64-bit register pair per word -- spilled, and each reload's wait also waited for the loads before it
+    const int ch = uni(ch_v);
+    const uint8_t *mrow = p.mod_t + (size_t)uni(mrow_off);
     const double bw = p.gn_bw, pw = p.gn_pw, nf = p.gn_nf;
     const double fc = p.gn_cf[ch];
     // the interferer terms of the lane's channels against channel ch: rows of the tables (coalesced over the lanes)
     const double *rowA = p.gn_A + (size_t)ch * p.cpad, *rowR = p.gn_R + (size_t)ch * p.cpad;
+    // (every load of the check is issued before the first value is used, none of them under a condition: a load inside
+    // `if (valid)` has to be waited for inside it -- one memory round trip per word, and they were most of the check's time)
     double A[W], B[W];
+    int se_w[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
         const int c = 64 * w + lane;
-        const bool valid = c < p.C && c != ch;
-        A[w] = 0.0; B[w] = 0.0;
-        if (valid) {
-            int se = (int)mrow[c];
-            se = se < 1 ? 1 : (se > 6 ? 6 : se);
-            const double pm = se <= 2 ? 1.0 : se == 3 ? 2.0 / 3 : se == 4 ? 17.0 / 25 : se == 5 ? 69.0 / 100 : 13.0 / 21;
-            A[w] = rowA[c];
-            B[w] = pm * rowR[c] * 5 / 3;
-        }
+        const int cc = c < p.C ? c : 0;   // a channel that exists: the value is dropped below
+        se_w[w] = (int)mrow[cc]; A[w] = rowA[cc]; B[w] = rowR[cc];
     }
     const double base = p.gn_link[4 * p.E];
     const double r = pw / bw;
@@ -1636,31 +1637,54 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
     const int hops = rec->hops;
     // the links' constants (effective length, its ratio to the span length, exp(2 att len) - 1, spans) for every hop at once:
     // lane h = hop h, read back per hop by readlane -- one memory round trip per check instead of one per hop
-    double lk0 = 0.0, lk1 = 0.0, lk2 = 0.0;
-    int lkn = 0;
-    if (lane < hops) {
-        const int lnk = (int)rec->link[lane];
+    double lk0, lk1, lk2;
+    int lkn;
+    {
+        const int lnk = (int)rec->link[lane < hops ? lane : 0];   // (lanes past the path's end read hop 0's constants and do not use them)
         lk0 = p.gn_link[4 * lnk]; lk1 = p.gn_link[4 * lnk + 1]; lk2 = p.gn_link[4 * lnk + 2];
         lkn = p.gn_nspans[lnk];
+    }
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int c = 64 * w + lane;
+        const bool valid = c < p.C && c != ch;
+        int se = se_w[w];
+        se = se < 1 ? 1 : (se > 6 ? 6 : se);
+        const double pm = se <= 2 ? 1.0 : se == 3 ? 2.0 / 3 : se == 4 ? 17.0 / 25 : se == 5 ? 69.0 / 100 : 13.0 / 21;
+        A[w] = valid ? A[w] : 0.0;
+        B[w] = valid ? pm * B[w] * 5 / 3 : 0.0;
     }
     // per hop only the interferer sum over the link's lit channels is wave-wide work; what follows from it -- the span's NLI
     // and ASE power and its share of 1 / GSNR: ~100 instructions with two divisions -- is done for ALL hops at once, lane h =
     // hop h, and the spans are then added hop by hop, span by span, as the reference adds them
     double sp = 0.0;   // lane h: sum_phi of hop h
-    for (int h = 0; h < hops; ++h) {
-        const int link = (int)rec->link[h];
-        const double ratio = readlane_d(lk1, h);
-        // per interferer asinh(..) - asinh(..) - phi_mod (B / |df|) 5/3 l_eff / L, as calculate_osnr.py:33-45 sums them; one wave sum
-        double sphi = 0.0;
+    SEC(11);
+    // three hops at a time: their occupancy words are requested together and their wave sums -- chains of dependent DPP steps --
+    // run interleaved (the sums themselves are formed as before, hop by hop)
+    constexpr int HB = 3;
+    for (int h0 = 0; h0 < hops; h0 += HB) {
+        double sphi[HB];
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const bool lit = !((occ[__mul24(link, W) + w] >> lane) & 1ull);   // (A, B are 0 on channels that do not exist)
-            sphi += lit ? (A[w] - (B[w] * ratio)) : 0.0;
+        for (int j = 0; j < HB; ++j) {
+            sphi[j] = 0.0;
+            const int h = h0 + j < hops ? h0 + j : hops - 1;   // (a hop past the path's end repeats the last one; its sum is not used)
+            const int link = (int)rec->link[h];
+            const double ratio = readlane_d(lk1, h);
+            // per interferer asinh(..) - asinh(..) - phi_mod (B / |df|) 5/3 l_eff / L, as calculate_osnr.py:33-45 sums them
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const bool lit = !((occ[__mul24(link, W) + w] >> lane) & 1ull);   // (A, B are 0 on channels that do not exist)
+                sphi[j] += lit ? (A[w] - (B[w] * ratio)) : 0.0;
+            }
         }
-        const double tot = base + wave_add_f64(sphi);
-        if (lane == h) sp = tot;
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+            const double tot = base + wave_add_f64(sphi[j]);
+            if (lane == h0 + j && h0 + j < hops) sp = tot;
+        }
     }
     double gv = 0.0;
+    SEC(12);
     {
         const double l_eff = lk0, e1 = lk2;
         const double power_nli_span = (r * r * r) * (8 / (27 * pi * fabs(beta_2))) * (gamma * gamma) * l_eff * sp * bw;
@@ -1670,9 +1694,13 @@ DEV double gn_gsnr(const OrlgPhyParams &p, const u64 *occ, const OrlgPathRec *re
     for (int h = 0; h < hops; ++h) {
         const double g = readlane_d(gv, h);
         const int ns = __builtin_amdgcn_readlane(lkn, h);
+#pragma unroll 4
         for (int sx = 0; sx < ns; ++sx) acc += g;
     }
-    return 10 * log10(1 / acc);
+    SEC(14);
+    const double gsnr_db = 10 * log10(1 / acc);
+    SEC(5);
+    return gsnr_db;
 }
 // DF: the instantiation that carries the periodic defragmentation (and the node-degree vectors of its cut metric); handles
 // without it run the other one, whose registers are not shared with code they never execute
@@ -1863,6 +1891,9 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
         }
     }
 
+    // GN gate: threshold q of the modulation levels on lane q (+inf beyond the last), read once per environment
+    double gn_thr_l = __longlong_as_double((long long)ORLG_INF_BITS);
+    if (GN && p.gn_on && lane < p.gn_nthr) gn_thr_l = p.gn_thr[lane];
     ReleaseAhead ra;
     ra.q = -1; ra.rec = 0u;
     // the next ring entry, requested one step ahead: lanes 0, 1 inter-arrival time, lanes 2, 3 holding time, lane 4 the request
@@ -2203,11 +2234,10 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_MAX_WAVES_PER_BLOCK, 4) void orlg_p
                 }
                 if (GN && p.gn_on && pass) {
                     // GN gate (not in the reference): every chosen channel must reach the level the table promised
-                    const uint8_t *mrow_g = p.mod_t + (size_t)(row * K + a_path) * p.cpad;
+                    const int mrow_g = (row * K + a_path) * p.cpad;
                     for (int ci = 0; ci < nsel && pass; ++ci) {
-                        const double gdb = gn_gsnr<W>(p, occ, rec, mrow_g, sel_ch[ci], lane);
-                        int level = 0;
-                        for (int q = 0; q < p.gn_nthr; ++q) level += gdb >= p.gn_thr[q] ? 1 : 0;
+                        const double gdb = gn_gsnr<W>(p, occ, rec, mrow_g, sel_ch[ci], lane SEC_ARGS);
+                        const int level = popc64(ballot(gdb >= gn_thr_l));   // thresholds reached (lane q: threshold q)
                         gn_last = gdb;
                         if (level < sel_cap[ci]) pass = false;
                     }

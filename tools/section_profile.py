@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--phy", default=None, help="profile the PhyRMSA kernel with this policy (bmfa, sapff, ...) instead")
     ap.add_argument("--defrag", action="store_true")
     ap.add_argument("--metrics", action="store_true", help="PhyRMSA: per-step number_cuts_total / rss_total_metric outputs")
+    ap.add_argument("--gn", action="store_true", help="PhyRMSA: the GN-model gate of the chosen channels inside the step")
     args = ap.parse_args()
     sys.path.insert(0, PKG)
     import build as orlg_build   # single-translation-unit build (csrc/orlg_unity.hip, W = 5: NSFNET-320 / US14-268)
@@ -37,7 +38,9 @@ def main():
         pairs, mod, gsnr = load_phy_tables("us14_k3")
         env = BatchedPhyRMSAEnv(load_topology("us14_3-paths_6-modulations"), args.batch, modulation_level=mod, connections_detail=pairs,
                                 gsnr=gsnr, load=1400, mean_service_holding_time=25, episode_length=200, seed=10,
-                                defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None)
+                                defrag_period=10 if args.defrag else None, number_moves=10 if args.defrag else None,
+                                **({"gn_gate": __import__("optical_rl_gym_amd").gn_gate_parameters(load_topology("us14_3-paths_6-modulations"))}
+                                   if args.gn else {}))
         names = ["idle/ticket", "state load", "policy: virtual layer", "policy: row metrics", "policy: channel selection", "provision",
                  "outputs", "next arrival + RNG", "defrag: grooming walk", "release: buffer / rebuild", "release apply (+ next scan)",
                  "defrag: grooming scan", "defrag: candidate scan", "state store", "defrag: candidate rounds", "defrag: candidate ranks"]
