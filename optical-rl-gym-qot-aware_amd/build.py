@@ -99,7 +99,20 @@ def _compile(name, src, extra, verbose):
 
 
 def build(force=False, verbose=True, jobs=None):
+    """Compile what is stale and link liborlg.so.  One builder at a time: the ranks of a multi-GPU launch all import the package
+    at once, and a stale tree must not be rebuilt by eight of them into the same object directory (the others wait for the
+    lock, then find the library fresh); the library appears under its name only when it is complete."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
     todo = [(n, s, x) for n, s, x in units() if force or _stale(n, x)]
     if not todo and os.path.exists(LIB) and not force and not needs_build():
         return LIB
@@ -109,10 +122,12 @@ def build(force=False, verbose=True, jobs=None):
         for f in futs:
             f.result()
     objs = [os.path.join(OBJ, n + ".o") for n, _, _ in units()]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    tmp = LIB + ".tmp%d" % os.getpid()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     if verbose:
-        print(" ".join(cmd), flush=True)
+        print(" ".join(cmd).replace(tmp, LIB), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)
     return LIB
 
 
