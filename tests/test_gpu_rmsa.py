@@ -465,29 +465,31 @@ def test_reseed_between_launches_vs_oracle(nsfnet, device_log_in_oracle, step_ke
     env.close()
 
 
-def test_group_kernel_deferred_link_statistics(nsfnet, device_log_in_oracle):
-    """Long launches with full statistics run the group kernel's instantiation that LOGS the links' float64 updates and works
+def test_deferred_link_statistics(nsfnet, device_log_in_oracle):
+    """Long launches with full statistics run the step kernels' instantiations that LOG the links' float64 updates and works
     them off one link per lane (group_link_replay): the same operations on the same values.  Against the instantiation that
     does them in place (ORLG_NO_DEFER, and launches below 16 steps) -- saved state byte for byte after every launch, a replay
     forced by a full log (load 300 on 100 slots: a link collects 40 updates within a launch) -- and against the oracle's link
     statistics."""
-    if STEP_KERNEL != "group":
-        pytest.skip("a test of the four-environments-per-wave kernel")
+    # (both step kernels defer: the wave-per-environment kernel replays with lane = link, link_replay<64>)
+    kernel = "group" if STEP_KERNEL == "group" else "wave"
+    plain, deferred = (("orlg_rmsa_group_kernel<2,2>", "orlg_rmsa_group_kernel<2,2,false,true>") if kernel == "group"
+                       else ("orlg_rmsa_kernel_ff<2,2>", "orlg_rmsa_kernel_ff<2,2,true>"))
     kw = dict(num_spectrum_resources=100, load=300, mean_service_holding_time=25, episode_length=300, seed=17,
               bit_rates=[25, 50, 75, 100])
     B = 10
     outs = ("act_path", "act_slot", "accepted")
-    a = make_batched(nsfnet, kw, B, step_kernel="group")
+    a = make_batched(nsfnet, kw, B, step_kernel=kernel)
     os.environ["ORLG_NO_DEFER"] = "1"
     try:
-        b = make_batched(nsfnet, kw, B, step_kernel="group")
+        b = make_batched(nsfnet, kw, B, step_kernel=kernel)
         ref_runs = [b.run("sap_ff", n, outputs=outs, auto_reset=True) for n in (700, 16, 333)]
-        assert b.last_kernel().startswith("orlg_rmsa_group_kernel<2,2>"), b.last_kernel()
+        assert b.last_kernel().startswith(plain), b.last_kernel()
         sb = b.save_state()
     finally:
         del os.environ["ORLG_NO_DEFER"]
     runs = [a.run("sap_ff", n, outputs=outs, auto_reset=True) for n in (700, 16, 333)]
-    assert a.last_kernel().startswith("orlg_rmsa_group_kernel<2,2,false,true>"), a.last_kernel()
+    assert a.last_kernel().startswith(deferred), a.last_kernel()
     for x, y in zip(runs, ref_runs):
         for k in outs:
             assert np.array_equal(x[k], y[k]), k
