@@ -52,6 +52,7 @@ struct orlg_env {
     int group_resident_df[ORLG_GROUP_WAVES + 1];   // ... of the instantiation with the link statistics deferred
     int group_df_lint, group_df_qtime, group_df_qdesc, group_df_wave_bytes, group_df_wpb;   // its LDS layout (no link-statistics slices)
     uint4 *llog;             // its log of link updates [B][E][64] (allocated with the first such launch)
+    uint32_t *progress;      // chunked tickets: chunks completed per quad in the current launch (allocated with the first such launch)
     size_t group_lds_bytes;
     int num_cu;
     uint32_t ticket_base;
@@ -302,7 +303,10 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     // per SIMD hide more latency); fewer when that would leave CUs idle or the last round mostly empty.  A round of w waves per
     // CU costs about w + 1.5 (measured: 10 waves per CU step 3 % more environments per second than 8); few rounds count whole.
     int wpb = wpb_max;
-    {
+    // (long launches of batches beyond one round of the full workgroup keep it: their rounds are evened out by tickets in chunks
+    // of steps, below -- the model here would trade resident waves for whole rounds)
+    const bool long_rounds = p.n_steps >= 256 && !hq && n_quads >= wpb_max * e->num_cu && !getenv("ORLG_NO_CHUNKS");
+    if (!long_rounds) {
         double best = 1e300;
         for (int w = wpb_max; w >= 1; --w) {
             const double rounds = (double)n_quads / ((double)e->num_cu * w);
@@ -310,6 +314,10 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
             const double cost = ((rounds < 3.0 || p.n_steps <= 16) ? std::ceil(rounds) : rounds + 0.5) * (w + 1.5);
             if (cost < best - 1e-9) { best = cost; wpb = w; }
         }
+    }
+    if (const char *ov = getenv("ORLG_GROUP_WPB")) {   // tooling override: waves per workgroup
+        const int v = atoi(ov);
+        if (v >= 1 && v <= wpb_max) wpb = v;
     }
     const size_t lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)wpb * wave_bytes;
     if (resident[wpb] <= 0) {
@@ -325,12 +333,48 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
     q.g_wave_bytes = wave_bytes;
     q.ticket_base = e->ticket_base;
     q.ticket_stride = p.n_steps <= 16 ? 1u : 0u;
-    if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads;  // one draw per quad of environments a wave takes on
+    // Tickets in chunks of steps (orlg_rmsa_group_kernel, work queue): when the batch is not a multiple of the resident waves, a
+    // launch's last round of whole-launch tickets runs at a fraction of the occupancy for a whole launch's time (B = 65 536 on 3072
+    // wave slots: 5.33 rounds, the last one 1/3 full and nearly as long as a full one).  With k chunks per quad the tail is one
+    // chunk long; a hand-off between waves costs a few microseconds (agent-scope release + acquire) against milliseconds of steps.
+    q.n_chunks = 1; q.chunk_steps = p.n_steps; q.progress = nullptr;
+    {
+        const int slots = nblocks * wpb;
+        int k = 1;
+        if (long_rounds && !q.ticket_stride && n_quads > slots) {   // (exactly one round: 1 116 with chunks against 1 131-1 140 M)
+            // Measured (NSFNET-320, 1000-step launches, M env-steps/s by chunks k = 1 / 2 / 3 / 4; r = quads / slots rounds):
+            //   B = 16 384 (r = 1.33):   853 / 1 090 / 1 131 / 1 178      B = 49 152 (r = 4):    1 151 / 1 250 / 1 212 / 1 240
+            //   B = 24 576 (r = 2):    1 139 / 1 136 / 1 234 / 1 234      B = 65 536 (r = 5.33): 1 206 / 1 259 / 1 249 / 1 235
+            //   B = 131 072 (r = 10.7): 1 282 with k = 1, 1 257 with k = 3: after many rounds the waves' finishing times have
+            //   spread and the last round is short by itself.
+            // A chunk boundary costs a quad ~0.55 % of a 1000-step launch (state store + load, release + acquire); whole rounds
+            // (r = 2, 4) gain as well: waves that start together stay in step -- all in the same refill at the same time -- and
+            // chunks of different quads break that up.  About eight rounds of tickets are enough:
+            k = (int)std::floor(8.0 * slots / n_quads + 0.5);
+            k = k < 1 ? 1 : (k > 4 ? 4 : k);
+            while (k > 1 && p.n_steps / k < 64) --k;
+        }
+        if (const char *ov = getenv("ORLG_GROUP_CHUNKS")) {   // tooling / tests: force the number of chunks (any batch)
+            const int v = atoi(ov);
+            if (v >= 1 && v <= 64 && !q.ticket_stride && !hq) k = v < p.n_steps ? v : p.n_steps;
+        }
+        if (k > 1) {
+            if (!e->progress) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->progress), ((size_t)p.B / 4 + 1) * sizeof(uint32_t)));
+                e->bufs.push_back(e->progress);
+            }
+            HIP_TRY(hipMemsetAsync(e->progress, 0, (size_t)n_quads * sizeof(uint32_t), e->stream));
+            q.chunk_steps = (p.n_steps + k - 1) / k;
+            q.n_chunks = (p.n_steps + q.chunk_steps - 1) / q.chunk_steps;
+            q.progress = e->progress;
+        }
+    }
+    if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads * (uint32_t)q.n_chunks;  // one draw per ticket a wave takes on
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());
-    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d%s> grid=%d block=%d lds=%zu", e->W, p.stats_level,
-             hq ? ",true" : df ? ",false,true" : "", nblocks, ORLG_WAVE * wpb, lds_bytes);
+    snprintf(e->last_kernel, sizeof(e->last_kernel), "orlg_rmsa_group_kernel<%d,%d%s> grid=%d block=%d lds=%zu chunks=%d", e->W, p.stats_level,
+             hq ? ",true" : df ? ",false,true" : "", nblocks, ORLG_WAVE * wpb, lds_bytes, q.n_chunks);
     return ORLG_OK;
 }
 
@@ -656,6 +700,7 @@ int orlg_create(const orlg_topology *t, const orlg_rmsa_config *c, int32_t batch
         e->group_lds_bytes = (size_t)p.l_shared_bytes + p.g_mt + 16 + (size_t)e->group_wpb * p.g_wave_bytes;
         for (int w = 0; w <= ORLG_GROUP_WAVES; w++) e->group_resident[w] = e->group_resident_hq[w] = e->group_resident_df[w] = 0;
         e->llog = nullptr;
+        e->progress = nullptr;
         {   // the instantiation that defers the link statistics keeps them in HBM: the same arrays without their slices
             int gd = up16(p.g_occ + 4 * p.NW * 8);
             e->group_df_lint = gd; gd = up16(gd + 4 * p.lint_stride * 4);

@@ -111,6 +111,11 @@ struct OrlgParams {
     uint32_t *ticket;
     uint32_t ticket_base;
     uint32_t ticket_stride;   // 1: static striding (env = wave, wave + waves, ...) instead of tickets: short launches
+    // long launches of the four-environments-per-wave kernel, tickets in CHUNKS of steps (n_chunks > 1): ticket t = chunk t / quads
+    // of quad t % quads -- a quad's launch is cut into n_chunks pieces that different waves may run, so the last round of
+    // tickets is short; progress[quad] = chunks of the quad completed in this launch (the hand-off between the waves)
+    int32_t n_chunks, chunk_steps;
+    uint32_t *progress;
     // per-wave LDS layout (byte offsets from the wave's base) and size
     int32_t l_occ, l_qtime, l_qdesc, l_mt, l_lstat, l_hist, l_lint, l_scratch, l_wsc, l_ring, l_wave_bytes;
     int32_t l_shared_bytes;   // tables + output pointer block, in front of the per-wave regions

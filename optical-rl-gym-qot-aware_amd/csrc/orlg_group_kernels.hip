@@ -299,25 +299,42 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     // ------------------------------------------------------------------ work queue over quads of environments
     // quad q = environments 4q .. 4q+3; the first quad of a wave is its own index, the rest come from the ticket counter
     // (long launches) or by striding (short ones), as in the wave-per-environment kernel
+    // A long launch hands its quads out in CHUNKS of steps (OrlgParams::n_chunks): with whole launches as tickets the last round
+    // of a batch that is not a multiple of the resident waves runs at a fraction of the occupancy for a whole launch's time
+    // (B = 65 536: 5.33 rounds); a chunk of a quad goes to whichever wave draws it, after the wave that ran the chunk before
+    // has published the quad's state (progress[quad]; release / acquire at agent scope: another CU, maybe another XCD).
     const int n_quads = (p.B + ORLG_GE - 1) / ORLG_GE;
+    const int n_chunks = p.n_chunks > 1 ? p.n_chunks : 1;
+    const int n_tix = n_quads * n_chunks;
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int n_static = n_waves < n_quads ? n_waves : n_quads;
-    int quad = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
-    if (quad >= n_quads) return;
+    const int n_static = n_waves < n_tix ? n_waves : n_tix;
+    int tix = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
+    if (tix >= n_tix) return;
     uint32_t nxt_tk = 0;
     for (bool first = true;; first = false) {
     if (!first) {
         if (p.ticket_stride) {
-            quad += n_waves;
-            if (quad >= n_quads) break;
+            tix += n_waves;
+            if (tix >= n_tix) break;
         } else {
             const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt_tk) - p.ticket_base;
-            if (tk >= (uint32_t)(n_quads - n_static)) break;
-            quad = n_static + (int)tk;
+            if (tk >= (uint32_t)(n_tix - n_static)) break;
+            tix = n_static + (int)tk;
         }
     }
+    int chunk = 0, quad = tix;
+    if (n_chunks > 1) { chunk = tix / n_quads; quad = tix - chunk * n_quads; }
+    const int t0 = n_chunks > 1 ? chunk * p.chunk_steps : 0;   // first step of this ticket within the launch
     SEC(1);  // state load
     if (!p.ticket_stride && lane == 0) nxt_tk = atomicAdd(p.ticket, 1u);
+    if (chunk > 0) {
+        // the quad's state as the previous chunk left it: one relaxed poll, one acquire, the wait for its invalidate -- then
+        // plain loads (MI355X_MICROARCH.md, inter-workgroup visibility)
+        if (lane == 0)
+            while (__hip_atomic_load(p.progress + quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)chunk) __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int env_raw = quad * ORLG_GE + g;
     const bool act = env_raw < p.B;          // rows past the batch's end idle (they load the last environment and store nothing)
     const int env = act ? env_raw : p.B - 1;
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     const int cidx = gl & 7;
     int req_base = tb.pair_base[req_src * N + req_dst];  // first path record of the pending request's node pair
 
-    const int n_iter = p.n_steps;
+    const int n_iter = n_chunks > 1 ? (p.n_steps - t0 < p.chunk_steps ? p.n_steps - t0 : p.chunk_steps) : p.n_steps;
     const int policy = p.policy;
     for (int t = 0; t < n_iter; ++t) {
         SEC(2);  // policy
@@ -567,7 +584,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         SEC(6);  // outputs
         // per-step outputs (first lane of the row)
         if (p.out_mask && act && gl == 0) {
-            const size_t o = (size_t)t * p.B + env;
+            const size_t o = (size_t)(t0 + t) * p.B + env;
             const int om = p.out_mask;
             if (om & (1 << ORLG_OUT_PATH)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_PATH])[o] = a_path;
             if (om & (1 << ORLG_OUT_SLOT)) ORLG_GPTR(int32_t, tb.outs[ORLG_OUT_SLOT])[o] = a_slot;
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         {
             const bool done = act && eproc == p.episode_length;
             if (act && gl == 0 && (p.out_mask & (1 << ORLG_OUT_DONE)))
-                ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_DONE])[(size_t)t * p.B + env] = done ? 1 : 0;
+                ORLG_GPTR(uint8_t, tb.outs[ORLG_OUT_DONE])[(size_t)(t0 + t) * p.B + env] = done ? 1 : 0;
             if (ballot(done && p.auto_reset)) {
                 // reset(only_episode_counters=True) with a pending service (rmsa_env.py:343-389)
                 if (done && p.auto_reset) {
@@ -769,6 +786,14 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
         }
     }
     wave_sync();
+    if (n_chunks > 1) {
+        // publish: this wave's stores complete, the XCD's L2 written back, then the flag (the explicit waits: the compiler may
+        // drop the one behind the release)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.progress + quad, (uint32_t)(chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     SEC(0);
     }  // work queue
     SEC_FLUSH;

@@ -87,3 +87,57 @@ def test_mixed_topology_groups_32768(name, device_log_in_oracle):
     red, _ = env.reduce_counters()
     assert red["num_envs"] == B and red["services_processed"] == 351 * B
     env.close()
+
+
+@pytest.mark.parametrize("B,n,outs", [(20004, 400, ("act_path", "act_slot", "accepted", "done")), (65536, 1000, ("accepted",))])
+def test_tickets_in_chunks_of_steps(device_log_in_oracle, B, n, outs):
+    """Long launches of batches beyond one round of resident waves hand a quad's launch out in CHUNKS of steps (the work queue of
+    orlg_rmsa_group_kernel: ticket = (quad, chunk); the wave that draws a chunk waits for the quad's previous chunk to be
+    published -- agent-scope release / acquire, the two waves may sit on different XCDs).  B = 20 004 (5 001 quads on 3 072 wave
+    slots: every wave hands quads over, under the uneven load of a last partial round; a partial last quad), three launches of
+    400 steps with per-step outputs (and the headline's batch, B = 65 536, three launches of 1000 steps), against the same launches with whole-launch tickets (ORLG_NO_CHUNKS): outputs at their
+    step's row, counters, link statistics and the saved state byte for byte; forced to 7 chunks as well; spot checks against
+    the oracle."""
+    import os
+    from optical_rl_gym_amd import BatchedRMSAEnv
+    nsfnet = load_topology("nsfnet_chen_5-paths_6-modulations")
+    kw = dict(num_spectrum_resources=320, load=50, mean_service_holding_time=25, episode_length=300, seed=901)
+
+    def drive(env_vars):
+        old = {k: os.environ.get(k) for k in ("ORLG_NO_CHUNKS", "ORLG_GROUP_CHUNKS")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env_vars)
+        try:
+            env = BatchedRMSAEnv(nsfnet, B, step_kernel="group", **kw)
+            runs = [env.run("sap_ff", n, outputs=outs, auto_reset=True) for _ in range(3)]
+            name = env.last_kernel()
+            res = (runs, env.save_state().copy(), {k: v.copy() for k, v in env.counters().items()},
+                   {k: v.copy() for k, v in env.link_stats().items()}, name)
+            env.close()
+            return res
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+
+    ref = drive({"ORLG_NO_CHUNKS": "1"})
+    assert ref[4].endswith("chunks=1"), ref[4]
+    for env_vars in ({}, {"ORLG_GROUP_CHUNKS": "7"}):
+        got = drive(env_vars)
+        assert not got[4].endswith("chunks=1"), got[4]
+        for x, y in zip(got[0], ref[0]):
+            for k in outs:
+                assert np.array_equal(x[k], y[k]), (env_vars, k)
+        assert np.array_equal(got[1], ref[1]), env_vars
+        for k in ref[2]:
+            assert np.array_equal(got[2][k], ref[2][k]), (env_vars, k)
+        for k in ref[3]:
+            assert np.array_equal(got[3][k], ref[3][k]), (env_vars, k)
+    for i in (0, 4999, 12345, B - 1):
+        o = oracle_env_from_kwargs(nsfnet, kw, seed=901 + i)
+        tr = o.run("sap_ff", 3 * n, reset_on_done=True)
+        got_acc = np.concatenate([r["accepted"][:, i] for r in ref[0]])
+        assert np.array_equal(got_acc, tr["accepted"]), i
+        o.close()
