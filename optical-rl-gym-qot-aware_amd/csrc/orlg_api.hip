@@ -369,7 +369,9 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
             q.progress = e->progress;
         }
     }
-    if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads * (uint32_t)q.n_chunks;  // one draw per ticket a wave takes on
+    // one draw per ticket a wave takes on (the next one is drawn when a ticket is taken up); with chunks every wave draws its first
+    // ticket as well
+    if (!q.ticket_stride) e->ticket_base += (uint32_t)n_quads * (uint32_t)q.n_chunks + (q.n_chunks > 1 ? (uint32_t)(nblocks * wpb) : 0u);
     dim3 grid(nblocks), block(ORLG_WAVE * wpb);
     hipLaunchKernelGGL(k, grid, block, lds_bytes, e->stream, q);
     HIP_TRY(hipGetLastError());

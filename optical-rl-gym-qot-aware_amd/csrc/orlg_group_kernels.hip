@@ -307,11 +307,15 @@ __global__ __launch_bounds__(ORLG_WAVE *ORLG_GROUP_WAVES, (ORLG_GROUP_WAVES + 3)
     const int n_chunks = p.n_chunks > 1 ? p.n_chunks : 1;
     const int n_tix = n_quads * n_chunks;
     const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int n_static = n_waves < n_tix ? n_waves : n_tix;
+    // (with chunks EVERY ticket is drawn, a wave's first one too: a ticket that waits for its predecessor must be able to count on
+    // a RUNNING wave holding it -- a statically assigned ticket of a workgroup that is not resident yet, because another kernel
+    // shares the device, would be waited for by the very waves that keep that workgroup out)
+    const int n_static = n_chunks > 1 ? 0 : (n_waves < n_tix ? n_waves : n_tix);
     int tix = (int)(blockIdx.x * (blockDim.x >> 6)) + wib;
-    if (tix >= n_tix) return;
+    if (n_chunks == 1 && tix >= n_tix) return;
     uint32_t nxt_tk = 0;
-    for (bool first = true;; first = false) {
+    if (n_chunks > 1 && lane == 0) nxt_tk = atomicAdd(p.ticket, 1u);
+    for (bool first = n_chunks == 1;; first = false) {
     if (!first) {
         if (p.ticket_stride) {
             tix += n_waves;
