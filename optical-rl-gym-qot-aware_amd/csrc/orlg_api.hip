@@ -352,7 +352,7 @@ static int launch_rmsa_group(orlg_env *e, const OrlgParams &p) {
             // chunks of different quads break that up.  About eight rounds of tickets are enough:
             k = (int)std::floor(8.0 * slots / n_quads + 0.5);
             k = k < 1 ? 1 : (k > 4 ? 4 : k);
-            while (k > 1 && p.n_steps / k < 64) --k;
+            while (k > 1 && p.n_steps / k < 128) --k;   // (a boundary costs the same whatever the chunk's length)
         }
         if (const char *ov = getenv("ORLG_GROUP_CHUNKS")) {   // tooling / tests: force the number of chunks (any batch)
             const int v = atoi(ov);
