@@ -67,6 +67,8 @@ def parse_args(argv=None):
                     "their quarter-batch launches would be mistaken for the record's own)")
     ap.add_argument("--only", default=None, choices=["headline", "rmsa_b4096", "phy", "phy_metrics", "phy_defrag", "phy_gn", "deeprmsa"],
                     help="run one workload only (profiling)")
+    ap.add_argument("--phy-chunk", type=int, default=1000, help="PhyRMSA sub-records: env-steps per launch per environment (a launch "
+                    "ends with its slowest environment: 250-step launches run 3-6 %% below 1000-step ones)")
     ap.add_argument("--mixed", action="store_true", help="configs[4]: NSFNET / JPN12 / US14 topology groups, one per rank (r %% 3)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: ranks report their shard through gloo (launcher test)")
     return ap.parse_args(argv)
@@ -224,7 +226,7 @@ def phy_record(clock, args, variant):
     import torch
     from conftest import load_phy_tables, load_topology
     from optical_rl_gym_amd import BatchedPhyRMSAEnv
-    B, chunk = 4096, 250
+    B, chunk = 4096, args.phy_chunk
     topo = load_topology("us14_3-paths_6-modulations")
     pairs, mod, gsnr = load_phy_tables("us14_k3")
     defrag = variant == "phy_defrag"
@@ -243,7 +245,7 @@ def phy_record(clock, args, variant):
         out = {"number_cuts_total": torch.empty((chunk, B), dtype=torch.float64, device=clock.dev),
                "rss_total_metric": torch.empty((chunk, B), dtype=torch.float64, device=clock.dev)}
     launch = lambda: env.run("bmfa", chunk, auto_reset=True, out=out)
-    for _ in range(12):   # 3000 steps: load 1400 needs a few thousand arrivals to fill the network
+    for _ in range(max(3, 3000 // chunk)):   # 3000 steps: load 1400 needs a few thousand arrivals to fill the network
         launch()
     # as many launches as make about one second
     clock.barrier()

@@ -32,10 +32,10 @@ OUT = os.path.join(ROOT, "gpurun_out", "profiles_out")
 WORK = {
     "headline": ("orlg_rmsa_group_kernel", "rmsa_b65536", 65536, 1000),
     "rmsa_b4096": ("orlg_rmsa_kernel_ff", "rmsa_b4096", 4096, 1000),
-    "phy": ("orlg_phy_kernel", "phy", 4096, 250),
-    "phy_metrics": ("orlg_phy_kernel", "phy_metrics", 4096, 250),
-    "phy_defrag": ("orlg_phy_kernel", "phy_defrag", 4096, 250),
-    "phy_gn": ("orlg_phy_kernel", "phy_gn", 4096, 250),
+    "phy": ("orlg_phy_kernel", "phy", 4096, 1000),
+    "phy_metrics": ("orlg_phy_kernel", "phy_metrics", 4096, 1000),
+    "phy_defrag": ("orlg_phy_kernel", "phy_defrag", 4096, 1000),
+    "phy_gn": ("orlg_phy_kernel", "phy_gn", 4096, 1000),
     "deeprmsa": ("orlg_rmsa_", "deeprmsa", 32768, 1),
 }
 PMC_PASSES = {
