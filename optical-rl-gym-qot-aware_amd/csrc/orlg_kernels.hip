@@ -243,7 +243,9 @@ __device__ __noinline__ int refill_requests_as(orlg_lds_u32 *mt, void *ring_iat_
     // The request stream is the same whatever a refill's size; what changes is WHEN the environments run dry: batches stepped
     // one launch per step (agent-driven) otherwise refill all at once every 62nd launch, one after the other behind the
     // workgroup's staging-buffer lock.
+#ifndef ORLG_EXP_NO_STAGGER   // (experiment: every environment refills in the same launch, the other 61 of 62 launches none)
     if (idx == ORLG_MT_N) { const int cap = 62 - env % 56; n = n > cap ? cap : n; }
+#endif
     uint32_t w[10];
     const int g0 = idx + 10 * lane;
 #pragma unroll
